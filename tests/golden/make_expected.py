@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Extracts the known-answer values the reference's RUnit tests hold for the
+hot path into tests/golden/expected.json (data only; no reference code).
+
+Run in the build container (needs /root/reference):
+    python tests/golden/make_expected.py
+Sources (reference inst/unitTests/):
+    test_generateCytosineReport.R:1-260, test_generateMhlReport.R:1-123,
+    test_simulateBam.R:53-87, test_generateBedReport.R:12-83,
+    test_preprocessBam.R:11-15
+plus the survey-time probe outputs recorded in SURVEY.md section 8c.
+"""
+import json
+import os
+import re
+
+REF = "/root/reference/inst/unitTests"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def blocks(fn):
+    """Yield (expr, value) source strings of every RUnit::checkEquals(expr, value) call."""
+    src = open(os.path.join(REF, fn)).read()
+    for m in re.finditer(r"RUnit::checkEquals\(", src):
+        i = m.end()
+        depth, args, cur = 1, [], []
+        while depth > 0:
+            ch = src[i]
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append("".join(cur))
+                cur = []
+            else:
+                cur.append(ch)
+            i += 1
+        args.append("".join(cur))
+        yield [re.sub(r"\s+", " ", a).strip() for a in args]
+
+
+def nums(s):
+    s = s.strip()
+    if s.startswith("c("):
+        s = s[2:-1]
+    return [float(x) if ("." in x or "e" in x.lower()) else int(x) for x in re.findall(r"-?\d+\.?\d*(?:[eE]-?\d+)?", s)]
+
+
+def collect(fn):
+    out = []
+    for a in blocks(fn):
+        if len(a) >= 2 and re.match(r"^(c\()?[-\d\s.,eE]+\)?$", a[1]):
+            out.append({"expr": a[0], "value": nums(a[1])})
+    return out
+
+
+exp = {
+    "_source": "reference inst/unitTests/*.R (RUnit known-answer values), extracted by tests/golden/make_expected.py",
+    "generateCytosineReport": collect("test_generateCytosineReport.R"),
+    "generateMhlReport": collect("test_generateMhlReport.R"),
+    "simulateBam": collect("test_simulateBam.R"),
+    "generateBedReport": collect("test_generateBedReport.R"),
+    # Recorded at survey time from the unmodified reference objects;
+    # not reproducible in this image (reference unbuildable), kept as extra pins.
+    "survey_probe": {
+        "amplicon010meth": {"templates": 500, "bytes": 190455, "pass": 48, "cg_thr": [478, 632, 6449],
+                            "cg_thr_strand_rows": [241, 237], "cg_nothr": [478, 683, 6398],
+                            "cx_nothr": [5936, 893, 43660], "cx_ctx_rows": [3949, 1509, 478]},
+        "amplicon100meth": {"pass": 473, "cg_thr": [454, 6325, 439]},
+        "amplicon000meth": {"pass": 5, "cg_thr": [543, 15, 6971]},
+        "dragen-pe-namesort-xg-xm": {"templates": 100, "cx_nothr": [3827, 435, 5214], "cx_ctx_rows": [2608, 920, 299]},
+        "capture": {"templates": 2968, "pass": 1020},
+    },
+}
+with open(os.path.join(HERE, "expected.json"), "w") as f:
+    json.dump(exp, f, indent=1)
+for k in ("generateCytosineReport", "generateMhlReport", "simulateBam", "generateBedReport"):
+    print(k, len(exp[k]))
