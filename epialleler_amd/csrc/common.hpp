@@ -1,0 +1,123 @@
+// Internal declarations shared by the engine's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/epihip.h"
+
+namespace epi {
+
+// ---- errors ---------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define EPI_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return ::epi::fail(_e == hipErrorOutOfMemory ? EPI_ERR_NOMEM : EPI_ERR_HIP,  \
+                         "%s failed: %s (%s:%d)", #expr, hipGetErrorName(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define EPI_TRY(expr) do { int _rc = (expr); if (_rc != EPI_OK) return _rc; } while (0)
+
+// ---- geometry ---------------------------------------------------------------
+constexpr int kTile = 1024;            // positions per CX tile (absolute grid)
+constexpr int kMhlTile = 512;          // positions per lMHL tile (56 B of LDS counters per position and strand)
+constexpr int kCxPlanes = 16;          // [strand 2][counter 8] u32 planes of kTile entries
+constexpr int64_t kPosBias = 1LL << 31;// makes (start + bias) non-negative for any int32 start; multiple of every tile size
+
+// counter slots inside one strand's 8 planes
+enum { SLOT_DOT = 0, SLOT_OTHER = 1, SLOT_H = 2, SLOT_h = 3, SLOT_X = 4, SLOT_x = 5, SLOT_Z = 6, SLOT_z = 7, SLOT_SKIP = 8 };
+
+struct Tile {            // one work item of the tile kernels
+  int64_t pos0;          // first position of the tile
+  int32_t rname;
+  int32_t row_lo, row_hi;// candidate rows: same rname, start in (pos0 - Lmax, pos0 + kTile)
+  int32_t slot;          // >=0: accumulate into shared slab slot instead of emitting
+};
+
+// ---- device buffers that grow on demand --------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes);   // keeps contents only if no growth is needed
+  void release();
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfEntry { double ms = 0; int64_t n = 0; };
+
+}  // namespace epi
+
+struct epi_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;       // default compute stream
+  hipStream_t copy_stream = nullptr;  // H2D staging stream
+  void *pinned[2] = {nullptr, nullptr};
+  size_t pinned_bytes = 0;
+  hipEvent_t pinned_done[2] = {nullptr, nullptr};
+  int32_t *h_scalars = nullptr;       // pinned scratch for small D2H reads (64 x int64)
+};
+
+struct epi_batch {
+  epi_engine *eng = nullptr;
+  int64_t n = 0, nbytes = 0;
+  const uint8_t *xm = nullptr;
+  const int64_t *off = nullptr;
+  const int32_t *rname = nullptr, *strand = nullptr, *start = nullptr;
+  bool owns = false;
+  epi::DevBuf own_xm, own_off, own_rname, own_strand, own_start;
+
+  // reusable workspace
+  epi::DevBuf stats;        // RowStats
+  epi::DevBuf row_cnt, row_off, scan_tmp;
+  epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
+  epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e;
+  epi::DevBuf misc;         // cursor etc.
+  epi::DevBuf mhl_m, mhl_h; // per-byte stretch sizes, per-row haplotype info
+  size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
+  size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)
+
+  // state of the last report (for fetch)
+  int last_kind = 0;        // 0 none, 1 cx, 2 mhl
+  int64_t last_nrow = 0;
+  int32_t last_ntiles = 0;
+
+  // multi-GPU shared tiles
+  std::vector<int64_t> shared_keys;
+  std::vector<int32_t> shared_owned;
+  epi::DevBuf d_shared_keys, d_shared_owned;
+  int32_t *d_slab = nullptr;
+};
+
+namespace epi {
+
+struct RowStats {          // filled by k_row_stats
+  int32_t max_len;
+  int32_t unsorted;        // !=0: some row violates (rname,start) order
+  int32_t bad_strand;      // !=0: strand not in {1,2}
+  int32_t bad_len;         // !=0: off not non-decreasing
+};
+
+hipStream_t pick_stream(epi_batch *b, void *stream);
+int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst);  // sync D2H of a few bytes
+
+// util kernels (util.hip)
+int scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total,
+                       DevBuf &tmp, hipStream_t s);
+
+// tile index (tiles.hip)
+int build_row_stats(epi_batch *b, hipStream_t s, RowStats *h_stats);
+int build_tiles(epi_batch *b, hipStream_t s, int32_t max_len, int32_t tile_positions, int32_t *ntiles_out);
+
+// profiling
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(const char *name, hipStream_t s);
+
+// context-string helpers (host)
+inline unsigned ctx_to_idx(unsigned char c) { return ((unsigned(c) + 2u) >> 2) & 15u; }   // src/epialleleR.h:28
+
+}  // namespace epi

@@ -1,0 +1,446 @@
+// rcpp_cx_report (src/rcpp_cx_report.cpp:34-159) on the GPU.
+//
+// The reference walks the sorted reads and, per base, emplaces
+// pos -> int[32] into an ordered map, flushing the map through the
+// majority-context rule (spit_results, :58-85) whenever a read starts beyond
+// everything seen so far.  For sorted input the flush timing does not change
+// the result: the output is the per-(rname,pos,strand) counter table pushed
+// through the rule, in (rname, pos, '+' before '-') order.
+//
+// Here a workgroup owns one tile of kTile consecutive positions (tiles.hip).
+// Its candidate rows are a contiguous row range; each wavefront takes rows
+// from it, streams the slice of the row that falls inside the tile with
+// coalesced dword loads and adds every base into u32 counters in LDS
+// ([strand][8 counters][kTile], 64 KiB) with ds_add_u32 -- consecutive lanes
+// hit consecutive banks, so the histogram is conflict-free by construction.
+// Only eight counters per (pos,strand) are ever read by the rule: '.', H, h,
+// X, x, Z, z and "everything else that counts toward coverage" (U/u and any
+// other nibble; nibble 9 counts twice because the reference's coverage slot is
+// slot 9, :126-127).  Coverage is their sum, so ONE LDS atomic per base.
+// After a barrier the same workgroup applies the rule, compacts its rows in
+// position order (block scan), grabs a span of the row pool with one global
+// atomic and writes (key, meth, unmeth).  A scan over per-tile row counts
+// then gives every tile its place in the final, ordered table (k_cx_gather).
+#include "common.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+namespace epi {
+
+constexpr int CX_WG = 512;                    // threads per tile workgroup (8 wavefronts)
+constexpr int CX_PPT = kTile / CX_WG;         // positions per thread in the emit phase
+static_assert(kTile % CX_WG == 0 && (CX_PPT == 1 || CX_PPT == 2 || CX_PPT == 4), "emit phase layout");
+
+// nibble -> counter slot (4 bits per code): see enum in common.hpp
+//   code:  0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15
+//   slot:  1 1 2 1 1 1 4 6 1 1  3  8  0  1  5  7
+constexpr uint64_t kSlotMap = 0x7510831164111211ull;
+
+__device__ __forceinline__ int readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), lane);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+struct CxArgs {
+  const uint8_t *xm;
+  const int64_t *off;
+  const int32_t *start, *strand, *pass;   // pass may be null
+  const Tile *tiles;
+  uint32_t ctx_mask;                      // bit k set: context k (2,6,7) is reported
+  uint32_t *pool_key, *pool_meth, *pool_unmeth;
+  uint32_t pool_cap;
+  uint32_t *cursor;                       // rows handed out so far (may exceed pool_cap: overflow)
+  uint32_t *tile_nrow, *tile_base;
+  int32_t *slab;                          // shared-tile counters [slot][16][kTile]
+};
+
+// Adds the in-tile slice of the rows [row_lo,row_hi) into the LDS counters.
+__device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = CX_WG / 64;
+  const int rot = (lane >> 3) & 3;          // byte order rotation: lanes l, l+8, l+16, l+24 (same bank at
+                                            // a 4-dword stride) work on different bytes of their dword
+  for (int rbase = td.row_lo + wave * 64; rbase < td.row_hi; rbase += NW * 64) {
+    const int r = rbase + lane;
+    int i_lo = 0, i_hi = 0, pbase = 0, sflag = 0, lc = 0;
+    int64_t o = 0;
+    if (r < td.row_hi) {
+      const int64_t st = a.start[r];
+      o = a.off[r];
+      const int64_t len = a.off[r + 1] - o;
+      const int64_t rel = td.pos0 - st;                  // row index of the tile's first position
+      const int64_t lo = rel > 0 ? rel : 0;
+      const int64_t hi = len < rel + kTile ? len : rel + kTile;
+      if (hi > lo) { i_lo = (int)lo; i_hi = (int)hi; }
+      pbase = (int)(-rel);                               // LDS position of row byte 0 (may be negative)
+      sflag = a.strand[r] - 1;
+      lc = (a.pass && a.pass[r] == 0) ? 8 : 0;           // !pass -> lower-case, rcpp_cx_report.cpp:118
+    }
+    const int nrows = td.row_hi - rbase < 64 ? td.row_hi - rbase : 64;
+    for (int j = 0; j < nrows; j++) {
+      const int jl = readlane_i32(i_lo, j), jh = readlane_i32(i_hi, j);
+      if (jl >= jh) continue;
+      const int64_t jo = readlane_i64(o, j);
+      const int jp = readlane_i32(pbase, j);
+      const uint32_t jlc = (uint32_t)readlane_i32(lc, j);
+      uint32_t *cb = cnt + readlane_i32(sflag, j) * (8 * kTile);
+      const int64_t b0 = jo + jl, b1 = jo + jh;          // byte range of the slice in xm
+      for (int64_t ad = (b0 & ~3LL) + 4 * lane; ad < b1; ad += 256) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(a.xm + ad);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int bb = (q + rot) & 3;
+          const int64_t bad = ad + bb;
+          if (bad >= b0 && bad < b1) {
+            const uint32_t code = ((w >> (8 * bb)) & 15u) | jlc;
+            const uint32_t slot = (uint32_t)(kSlotMap >> (4 * code)) & 15u;
+            if (slot != SLOT_SKIP) {
+              const int p = jp + (int)(bad - jo);
+              atomicAdd(&cb[slot * kTile + p], code == 9u ? 2u : 1u);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// The reference's majority rule on one (pos,strand): returns context 2/6/7 or 0 (no row).
+__device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, uint32_t *meth, uint32_t *unmeth) {
+  const uint32_t nH = c[SLOT_H] + c[SLOT_h], nX = c[SLOT_X] + c[SLOT_x], nZ = c[SLOT_Z] + c[SLOT_z];
+  const uint32_t cov = c[SLOT_DOT] + c[SLOT_OTHER] + nH + nX + nZ;
+  if (cov == 0) return 0;                                 // :62
+  const uint32_t half = cov >> 1;                         // :63
+  int k;
+  if (c[SLOT_DOT] > half) return 0;                       // :64
+  else if (nH > half) { k = 2; *meth = c[SLOT_H]; *unmeth = c[SLOT_h]; }   // :65
+  else if (nX > half) { k = 6; *meth = c[SLOT_X]; *unmeth = c[SLOT_x]; }   // :67
+  else if (nZ > half) { k = 7; *meth = c[SLOT_Z]; *unmeth = c[SLOT_z]; }   // :69
+  else return 0;                                          // :71
+  return ((ctx_mask >> k) & 1u) ? k : 0;                  // :72
+}
+
+// Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
+__device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = CX_WG / 64;
+  const int p0 = threadIdx.x * CX_PPT;
+  uint32_t key[2 * CX_PPT], me[2 * CX_PPT], un[2 * CX_PPT];   // statically indexed (fully unrolled): stay in VGPRs
+  bool ok[2 * CX_PPT];
+  int nr = 0;
+#pragma unroll
+  for (int q = 0; q < CX_PPT; q++) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      uint32_t c[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * kTile + p0 + q];
+      uint32_t m = 0, u = 0;
+      const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
+      ok[q * 2 + s] = ctx != 0;
+      key[q * 2 + s] = ((uint32_t)(p0 + q) << 4) | ((uint32_t)s << 3) | (uint32_t)ctx;
+      me[q * 2 + s] = m;
+      un[q * 2 + s] = u;
+      nr += ctx != 0;
+    }
+  }
+  // block-wide exclusive scan of nr
+  uint32_t inc = (uint32_t)nr;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
+    s_scan[NW] = acc;
+    uint32_t base = 0;
+    if (acc) base = atomicAdd(a.cursor, acc);
+    s_scan[NW + 1] = base;
+    a.tile_nrow[tile] = acc;
+    a.tile_base[tile] = base;
+  }
+  __syncthreads();
+  const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
+  const uint32_t ex = inc - (uint32_t)nr + s_scan[wave];
+  if ((uint64_t)base + total <= a.pool_cap) {
+    uint32_t w = base + ex;
+#pragma unroll
+    for (int i = 0; i < 2 * CX_PPT; i++) {
+      if (ok[i]) {
+        a.pool_key[w] = key[i];
+        a.pool_meth[w] = me[i];
+        a.pool_unmeth[w] = un[i];
+        w++;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(CX_WG) void k_cx_tiles(CxArgs a) {
+  __shared__ uint32_t cnt[kCxPlanes * kTile];
+  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  const int tile = blockIdx.x;
+  uint4 *z = reinterpret_cast<uint4 *>(cnt);
+  for (int i = threadIdx.x; i < kCxPlanes * kTile / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const Tile td = a.tiles[tile];
+  cx_accumulate(a, td, cnt);
+  __syncthreads();
+  if (td.slot >= 0) {
+    // shared with another rank (or split over several work items): hand the raw counters over
+    int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * kTile);
+    for (int i = threadIdx.x; i < kCxPlanes * kTile; i += CX_WG) {
+      const uint32_t v = cnt[i];
+      if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
+    }
+    if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+    return;
+  }
+  cx_emit(a, tile, cnt, s_scan);
+}
+
+// Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
+__global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned, int ntiles) {
+  __shared__ uint32_t cnt[kCxPlanes * kTile];
+  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  const int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const Tile td = a.tiles[tile];
+  if (td.slot < 0 || !owned[td.slot]) return;
+  const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * kTile);
+  for (int i = threadIdx.x; i < kCxPlanes * kTile; i += CX_WG) cnt[i] = (uint32_t)src[i];
+  __syncthreads();
+  cx_emit(a, tile, cnt, s_scan);
+}
+
+// Output row i -> its tile (binary search in the exclusive scan of tile row counts) -> decode.
+__global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
+                                                    const uint32_t *__restrict__ tile_base, int32_t ntiles, int64_t nrow,
+                                                    const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_meth,
+                                                    const uint32_t *__restrict__ pool_unmeth, int32_t *__restrict__ o_rname,
+                                                    int32_t *__restrict__ o_strand, int32_t *__restrict__ o_pos,
+                                                    int32_t *__restrict__ o_ctx, int32_t *__restrict__ o_meth,
+                                                    int32_t *__restrict__ o_unmeth) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nrow) return;
+  int32_t lo = 0, hi = ntiles;                 // last tile with tile_out[t] <= i
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if ((int64_t)tile_out[mid] <= i) lo = mid; else hi = mid;
+  }
+  const Tile td = tiles[lo];
+  const uint32_t src = tile_base[lo] + (uint32_t)(i - tile_out[lo]);
+  const uint32_t key = pool_key[src];
+  o_rname[i] = td.rname;
+  o_strand[i] = 1 + (int32_t)((key >> 3) & 1u);
+  o_pos[i] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
+  o_ctx[i] = (int32_t)(key & 7u);
+  o_meth[i] = (int32_t)pool_meth[src];
+  o_unmeth[i] = (int32_t)pool_unmeth[src];
+}
+
+static int ensure_pool(epi_batch *b, size_t rows) {
+  if (rows <= b->pool_cap && b->pool_key.p) return EPI_OK;
+  EPI_TRY(b->pool_key.ensure(rows * 4));
+  EPI_TRY(b->pool_a.ensure(rows * 4));
+  EPI_TRY(b->pool_b.ensure(rows * 4));
+  b->pool_cap = rows;
+  return EPI_OK;
+}
+
+}  // namespace epi
+
+using namespace epi;
+
+extern "C" {
+
+int epi_tile_positions(void) { return kTile; }
+
+int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx, void *stream, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_dev: NULL argument");
+  *nrow_out = 0;
+  b->last_kind = 0;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+
+  uint32_t ctx_mask = 0;                                   // rcpp_cx_report.cpp:88-91
+  for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
+
+  RowStats st;
+  EPI_TRY(build_row_stats(b, s, &st));
+  if (st.unsorted)
+    return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start); the reference requires a pre-sorted dataset "
+                                  "(src/rcpp_cx_report.cpp:19)");
+  int32_t nt = 0;
+  EPI_TRY(build_tiles(b, s, st.max_len, kTile, &nt));
+  b->last_ntiles = nt;
+  if (nt == 0) { b->last_kind = 1; b->last_nrow = 0; return EPI_OK; }
+
+  EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
+  EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
+  EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
+  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * (kTile / 4) + 65536));
+  uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
+
+  CxArgs a;
+  a.xm = b->xm; a.off = b->off; a.start = b->start; a.strand = b->strand; a.pass = d_pass;
+  a.tiles = b->tiles.as<Tile>();
+  a.ctx_mask = ctx_mask;
+  a.cursor = cursor;
+  a.tile_nrow = b->tile_nrow.as<uint32_t>();
+  a.tile_base = b->tile_base.as<uint32_t>();
+  a.slab = b->d_slab;
+  const int32_t nshared = (int32_t)b->shared_keys.size();
+
+  // Shared tiles are emitted later (epi_batch_cx_finish_shared) into the same pool: keep room for them.
+  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * kTile : 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    a.pool_key = b->pool_key.as<uint32_t>();
+    a.pool_meth = b->pool_a.as<uint32_t>();
+    a.pool_unmeth = b->pool_b.as<uint32_t>();
+    a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
+    EPI_HIP(hipMemsetAsync(cursor, 0, 8, s));
+    prof_begin("cx_tiles", s);
+    hipLaunchKernelGGL(k_cx_tiles, dim3((unsigned)nt), dim3(CX_WG), 0, s, a);
+    prof_end("cx_tiles", s);
+    EPI_HIP(hipGetLastError());
+    uint32_t used = 0;
+    EPI_TRY(read_scalars(b, s, cursor, 4, &used));
+    if ((size_t)used + headroom <= a.pool_cap) break;
+    if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
+    EPI_TRY(ensure_pool(b, (size_t)used + (used >> 4) + 1024 + headroom));   // exact need is known now: rerun once
+    if (nshared > 0)   // the rerun adds into the slab again
+      EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * kTile * 4, s));
+  }
+  if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
+
+  uint32_t *d_total = b->misc.as<uint32_t>() + 2;
+  EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
+  uint32_t total = 0;
+  EPI_TRY(read_scalars(b, s, d_total, 4, &total));
+  b->last_kind = 1;
+  b->last_nrow = total;
+  *nrow_out = total;
+  return EPI_OK;
+}
+
+// Second half of a sharded report: the slab has been sum-reduced across ranks;
+// emit the shared tiles this rank owns, then order all rows.
+int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_finish_shared: NULL argument");
+  if (b->last_kind != 3) return fail(EPI_ERR_STATE, "epi_batch_cx_finish_shared without a sharded epi_batch_cx_report_dev");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+  const int32_t nt = b->last_ntiles;
+  uint32_t ctx_mask = 0;
+  for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
+  uint32_t *cursor = b->misc.as<uint32_t>() + 1;
+  CxArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tiles = b->tiles.as<Tile>();
+  a.ctx_mask = ctx_mask;
+  a.cursor = cursor;
+  a.tile_nrow = b->tile_nrow.as<uint32_t>();
+  a.tile_base = b->tile_base.as<uint32_t>();
+  a.slab = b->d_slab;
+  a.pool_key = b->pool_key.as<uint32_t>();
+  a.pool_meth = b->pool_a.as<uint32_t>();
+  a.pool_unmeth = b->pool_b.as<uint32_t>();
+  a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
+  hipLaunchKernelGGL(k_cx_emit_slab, dim3((unsigned)nt), dim3(CX_WG), 0, s, a, b->d_shared_owned.as<int32_t>(), nt);
+  EPI_HIP(hipGetLastError());
+  {
+    uint32_t used = 0;   // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
+    EPI_TRY(read_scalars(b, s, cursor, 4, &used));
+    if (used > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
+  }
+  uint32_t *d_total = b->misc.as<uint32_t>() + 2;
+  EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
+  uint32_t total = 0;
+  EPI_TRY(read_scalars(b, s, d_total, 4, &total));
+  b->last_kind = 1;
+  b->last_nrow = total;
+  *nrow_out = total;
+  return EPI_OK;
+}
+
+int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
+                            int32_t *d_slab) {
+  if (!b || nshared < 0 || (nshared > 0 && (!h_keys || !h_owned || !d_slab)))
+    return fail(EPI_ERR_ARG, "epi_batch_cx_set_shared: bad arguments");
+  for (int32_t i = 1; i < nshared; i++)
+    if (h_keys[i - 1] >= h_keys[i]) return fail(EPI_ERR_ARG, "epi_batch_cx_set_shared: keys must be strictly increasing");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  b->shared_keys.assign(h_keys, h_keys + nshared);
+  b->shared_owned.assign(h_owned, h_owned + nshared);
+  b->d_slab = nshared > 0 ? d_slab : nullptr;
+  if (nshared > 0) {
+    EPI_TRY(b->d_shared_keys.ensure((size_t)nshared * 8));
+    EPI_TRY(b->d_shared_owned.ensure((size_t)nshared * 4));
+    EPI_HIP(hipMemcpy(b->d_shared_keys.p, h_keys, (size_t)nshared * 8, hipMemcpyHostToDevice));
+    EPI_HIP(hipMemcpy(b->d_shared_owned.p, h_owned, (size_t)nshared * 4, hipMemcpyHostToDevice));
+  }
+  return EPI_OK;
+}
+
+int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int64_t *last_key) {
+  if (!b || !first_key || !last_key) return fail(EPI_ERR_ARG, "epi_batch_tile_key_range: NULL argument");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+  *first_key = 0; *last_key = -1;              // empty range
+  RowStats st;
+  EPI_TRY(build_row_stats(b, s, &st));
+  if (st.unsorted) return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start)");
+  int32_t nt = 0;
+  EPI_TRY(build_tiles(b, s, st.max_len, kTile, &nt));
+  if (nt == 0) return EPI_OK;
+  Tile t0, t1;
+  EPI_TRY(read_scalars(b, s, b->tiles.as<Tile>(), sizeof(Tile), &t0));
+  EPI_TRY(read_scalars(b, s, b->tiles.as<Tile>() + (nt - 1), sizeof(Tile), &t1));
+  auto key = [](const Tile &t) { return ((int64_t)t.rname << 32) | (int64_t)(uint32_t)((t.pos0 + kPosBias) / kTile); };
+  *first_key = key(t0);
+  *last_key = key(t1);
+  return EPI_OK;
+}
+
+int epi_batch_cx_fetch_dev(epi_batch *b, int32_t *const d_cols[6], void *stream) {
+  if (!b || !d_cols) return fail(EPI_ERR_ARG, "epi_batch_cx_fetch_dev: NULL argument");
+  if (b->last_kind != 1) return fail(EPI_ERR_STATE, "epi_batch_cx_fetch_dev: no finished CX report on this batch");
+  if (b->last_nrow == 0) return EPI_OK;
+  for (int i = 0; i < 6; i++) if (!d_cols[i]) return fail(EPI_ERR_ARG, "epi_batch_cx_fetch_dev: NULL column");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+  const unsigned nb = (unsigned)((b->last_nrow + 255) / 256);
+  hipLaunchKernelGGL(k_cx_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
+                     b->tile_base.as<uint32_t>(), b->last_ntiles, b->last_nrow, b->pool_key.as<uint32_t>(),
+                     b->pool_a.as<uint32_t>(), b->pool_b.as<uint32_t>(), d_cols[0], d_cols[1], d_cols[2], d_cols[3],
+                     d_cols[4], d_cols[5]);
+  EPI_HIP(hipGetLastError());
+  return EPI_OK;
+}
+
+int epi_batch_cx_fetch_host(epi_batch *b, int32_t *const h_cols[6], void *stream) {
+  if (!b || !h_cols) return fail(EPI_ERR_ARG, "epi_batch_cx_fetch_host: NULL argument");
+  if (b->last_kind != 1) return fail(EPI_ERR_STATE, "epi_batch_cx_fetch_host: no finished CX report on this batch");
+  const int64_t nrow = b->last_nrow;
+  if (nrow == 0) return EPI_OK;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+  EPI_TRY(b->pool_c.ensure((size_t)nrow * 4 * 6));
+  int32_t *d = b->pool_c.as<int32_t>();
+  int32_t *cols[6];
+  for (int i = 0; i < 6; i++) cols[i] = d + (int64_t)i * nrow;
+  EPI_TRY(epi_batch_cx_fetch_dev(b, cols, s));
+  for (int i = 0; i < 6; i++)
+    EPI_HIP(hipMemcpyAsync(h_cols[i], cols[i], (size_t)nrow * 4, hipMemcpyDeviceToHost, s));
+  EPI_HIP(hipStreamSynchronize(s));
+  return EPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// Engine plumbing: errors, device buffers, engine/batch lifetime, pinned
+// double-buffered upload, small synchronous read-backs, HIP-event profiling.
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+
+namespace epi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap && p) return EPI_OK;
+  if (bytes == 0) bytes = 16;
+  size_t want = bytes + (bytes >> 3) + 256;   // a little slack so steady-state calls never reallocate
+  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  EPI_HIP(hipMalloc(&p, want));
+  cap = want;
+  return EPI_OK;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+hipStream_t pick_stream(epi_batch *b, void *stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : b->eng->stream;
+}
+
+int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst) {
+  if (bytes > 512) return fail(EPI_ERR_ARG, "read_scalars: too large");
+  EPI_HIP(hipMemcpyAsync(b->eng->h_scalars, d_src, bytes, hipMemcpyDeviceToHost, s));
+  EPI_HIP(hipStreamSynchronize(s));
+  memcpy(h_dst, b->eng->h_scalars, bytes);
+  return EPI_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+struct Pending { std::string name; hipEvent_t a, b; };
+static std::vector<Pending> g_pending;
+static std::map<std::string, ProfEntry> g_prof;
+static std::map<std::string, hipEvent_t> g_open;
+
+void prof_begin(const char *name, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_open[name] = e;
+}
+
+void prof_end(const char *name, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = g_open.find(name);
+  if (it == g_open.end()) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_pending.push_back({name, it->second, e});
+  g_open.erase(it);
+}
+
+static void prof_drain() {
+  for (auto &p : g_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      g_prof[p.name].ms += ms;
+      g_prof[p.name].n += 1;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  g_pending.clear();
+}
+
+}  // namespace epi
+
+using namespace epi;
+
+extern "C" {
+
+const char *epi_last_error(void) { return g_err; }
+int epi_version(void) { return 100; }
+
+void epi_prof_enable(int on) { g_prof_on = on != 0; }
+
+int epi_prof_get(const char *name, double *ms_total, int64_t *launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_drain();
+  auto it = g_prof.find(name);
+  if (it == g_prof.end()) { if (ms_total) *ms_total = 0; if (launches) *launches = 0; return EPI_OK; }
+  if (ms_total) *ms_total = it->second.ms;
+  if (launches) *launches = it->second.n;
+  return EPI_OK;
+}
+
+void epi_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_drain();
+  g_prof.clear();
+}
+
+int epi_engine_create(int device, epi_engine **out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_engine_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(EPI_ERR_NODEVICE, "no HIP device available (%s); libepihip has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorName(e));
+  if (device < 0 || device >= ndev) return fail(EPI_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+  EPI_HIP(hipSetDevice(device));
+  epi_engine *eng = new epi_engine();
+  eng->device = device;
+  EPI_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+  EPI_HIP(hipStreamCreateWithFlags(&eng->copy_stream, hipStreamNonBlocking));
+  EPI_HIP(hipHostMalloc(reinterpret_cast<void **>(&eng->h_scalars), 512, hipHostMallocDefault));
+  *out = eng;
+  return EPI_OK;
+}
+
+void epi_engine_destroy(epi_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (int i = 0; i < 2; i++) {
+    if (e->pinned[i]) (void)hipHostFree(e->pinned[i]);
+    if (e->pinned_done[i]) (void)hipEventDestroy(e->pinned_done[i]);
+  }
+  if (e->h_scalars) (void)hipHostFree(e->h_scalars);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  delete e;
+}
+
+int epi_engine_device(const epi_engine *e) { return e ? e->device : -1; }
+
+// Host -> HBM through two pinned staging buffers: the CPU fills buffer k+1
+// while the DMA engine drains buffer k (hipMemcpyAsync on the copy stream).
+static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t bytes) {
+  const size_t chunk = 32u << 20;
+  if (!eng->pinned[0]) {
+    for (int i = 0; i < 2; i++) {
+      EPI_HIP(hipHostMalloc(&eng->pinned[i], chunk, hipHostMallocDefault));
+      EPI_HIP(hipEventCreateWithFlags(&eng->pinned_done[i], hipEventDisableTiming));
+    }
+    eng->pinned_bytes = chunk;
+  }
+  size_t done = 0;
+  int k = 0;
+  while (done < bytes) {
+    size_t len = bytes - done < chunk ? bytes - done : chunk;
+    EPI_HIP(hipEventSynchronize(eng->pinned_done[k]));   // buffer k free again (no-op before first use)
+    memcpy(eng->pinned[k], static_cast<const char *>(h_src) + done, len);
+    EPI_HIP(hipMemcpyAsync(static_cast<char *>(d_dst) + done, eng->pinned[k], len, hipMemcpyHostToDevice, eng->copy_stream));
+    EPI_HIP(hipEventRecord(eng->pinned_done[k], eng->copy_stream));
+    done += len;
+    k ^= 1;
+  }
+  EPI_HIP(hipStreamSynchronize(eng->copy_stream));
+  return EPI_OK;
+}
+
+int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const int32_t *rname,
+                     const int32_t *strand, const int32_t *start, int64_t n, epi_batch **out) {
+  if (!e || !out) return fail(EPI_ERR_ARG, "epi_batch_upload: NULL engine/out");
+  *out = nullptr;
+  if (n < 0 || n > 0x7FFFFFF0LL) return fail(EPI_ERR_ARG, "epi_batch_upload: n=%lld out of range", (long long)n);
+  if (!off) return fail(EPI_ERR_ARG, "epi_batch_upload: off is NULL");
+  if (n > 0 && (!rname || !strand || !start)) return fail(EPI_ERR_ARG, "epi_batch_upload: NULL column");
+  const int64_t nbytes = off[n] - off[0];
+  if (off[0] != 0) return fail(EPI_ERR_ARG, "epi_batch_upload: off[0] must be 0");
+  if (nbytes < 0 || (nbytes > 0 && !xm)) return fail(EPI_ERR_ARG, "epi_batch_upload: bad xm/off");
+  EPI_HIP(hipSetDevice(e->device));
+  epi_batch *b = new epi_batch();
+  b->eng = e;
+  b->n = n;
+  b->nbytes = nbytes;
+  b->owns = true;
+  int rc = EPI_OK;
+  do {
+    const size_t cap = ((size_t)nbytes + 15) / 16 * 16 + 64;
+    if ((rc = b->own_xm.ensure(cap))) break;
+    if ((rc = b->own_off.ensure((size_t)(n + 1) * 8))) break;
+    if ((rc = b->own_rname.ensure((size_t)n * 4 + 4))) break;
+    if ((rc = b->own_strand.ensure((size_t)n * 4 + 4))) break;
+    if ((rc = b->own_start.ensure((size_t)n * 4 + 4))) break;
+    if (hipMemsetAsync(static_cast<char *>(b->own_xm.p) + nbytes, 0xFB, cap - nbytes, e->copy_stream) != hipSuccess) {
+      rc = fail(EPI_ERR_HIP, "memset failed"); break;
+    }
+    if (nbytes && (rc = staged_upload(e, b->own_xm.p, xm, (size_t)nbytes))) break;
+    if ((rc = staged_upload(e, b->own_off.p, off, (size_t)(n + 1) * 8))) break;
+    if (n) {
+      if ((rc = staged_upload(e, b->own_rname.p, rname, (size_t)n * 4))) break;
+      if ((rc = staged_upload(e, b->own_strand.p, strand, (size_t)n * 4))) break;
+      if ((rc = staged_upload(e, b->own_start.p, start, (size_t)n * 4))) break;
+    }
+  } while (0);
+  if (rc) { epi_batch_free(b); return rc; }
+  b->xm = b->own_xm.as<uint8_t>();
+  b->off = b->own_off.as<int64_t>();
+  b->rname = b->own_rname.as<int32_t>();
+  b->strand = b->own_strand.as<int32_t>();
+  b->start = b->own_start.as<int32_t>();
+  *out = b;
+  return EPI_OK;
+}
+
+int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int64_t nbytes,
+                    const int64_t *d_off, const int32_t *d_rname, const int32_t *d_strand,
+                    const int32_t *d_start, int64_t n, epi_batch **out) {
+  if (!e || !out) return fail(EPI_ERR_ARG, "epi_batch_adopt: NULL engine/out");
+  *out = nullptr;
+  if (n < 0 || n > 0x7FFFFFF0LL) return fail(EPI_ERR_ARG, "epi_batch_adopt: n out of range");
+  if (!d_off || (n > 0 && (!d_rname || !d_strand || !d_start))) return fail(EPI_ERR_ARG, "epi_batch_adopt: NULL column");
+  if (nbytes < 0 || (nbytes > 0 && !d_xm)) return fail(EPI_ERR_ARG, "epi_batch_adopt: bad xm");
+  if ((reinterpret_cast<uintptr_t>(d_xm) & 15) != 0) return fail(EPI_ERR_ARG, "epi_batch_adopt: d_xm must be 16-byte aligned");
+  if (xm_capacity < (nbytes + 15) / 16 * 16)
+    return fail(EPI_ERR_ARG, "epi_batch_adopt: xm_capacity %lld < nbytes rounded up to 16 (%lld)",
+                (long long)xm_capacity, (long long)((nbytes + 15) / 16 * 16));
+  epi_batch *b = new epi_batch();
+  b->eng = e;
+  b->n = n;
+  b->nbytes = nbytes;
+  b->owns = false;
+  b->xm = d_xm;
+  b->off = d_off;
+  b->rname = d_rname;
+  b->strand = d_strand;
+  b->start = d_start;
+  *out = b;
+  return EPI_OK;
+}
+
+void epi_batch_free(epi_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->eng->device);
+  DevBuf *bufs[] = {&b->own_xm, &b->own_off, &b->own_rname, &b->own_strand, &b->own_start, &b->stats,
+                    &b->row_cnt, &b->row_off, &b->scan_tmp, &b->tiles, &b->tile_nrow, &b->tile_base,
+                    &b->tile_out, &b->pool_key, &b->pool_a, &b->pool_b, &b->pool_c, &b->pool_d, &b->pool_e,
+                    &b->misc, &b->mhl_m, &b->mhl_h, &b->d_shared_keys, &b->d_shared_owned};
+  for (DevBuf *d : bufs) d->release();
+  delete b;
+}
+
+int64_t epi_batch_nrows(const epi_batch *b) { return b ? b->n : -1; }
+
+void epi_cx_table_free(epi_cx_table *t) {
+  if (!t) return;
+  free(t->rname); free(t->strand); free(t->pos); free(t->context); free(t->meth); free(t->unmeth);
+  memset(t, 0, sizeof(*t));
+}
+
+void epi_mhl_table_free(epi_mhl_table *t) {
+  if (!t) return;
+  free(t->rname); free(t->strand); free(t->pos); free(t->context); free(t->coverage);
+  free(t->length); free(t->lmhl);
+  memset(t, 0, sizeof(*t));
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+/*
+ * epihip.h -- C ABI of the MI355X-native per-read methylation-call aggregation
+ * engine (libepihip.so).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The four "drop-in" entry points replace, one for one, the native functions
+ * behind the reference's .Call stubs (BBCG/epialleleR v1.13.4):
+ *
+ *   epi_threshold_reads  <-  rcpp_threshold_reads  src/rcpp_threshold_reads.cpp:15-74
+ *                            (.Call "_epialleleR_rcpp_threshold_reads", R/RcppExports.R:64-66)
+ *   epi_get_xm_beta      <-  rcpp_get_xm_beta      src/rcpp_get_xm_beta.cpp:10-43
+ *                            (.Call "_epialleleR_rcpp_get_xm_beta",     R/RcppExports.R:28-30)
+ *   epi_cx_report        <-  rcpp_cx_report        src/rcpp_cx_report.cpp:34-159
+ *                            (.Call "_epialleleR_rcpp_cx_report",       R/RcppExports.R:12-14)
+ *   epi_mhl_report       <-  rcpp_mhl_report       src/rcpp_mhl_report.cpp:46-228
+ *                            (.Call "_epialleleR_rcpp_mhl_report",      R/RcppExports.R:40-42)
+ *
+ * Input layout (what an R/Rcpp shim gathers from the data.frame + seqxm_xptr,
+ * see INTEGRATION.md): templates in ROW order (i.e. already sorted by
+ * (rname,start) as .readBam leaves them, R/internal.R:193-195):
+ *   xm[off[n]]   packed SEQXM bytes, (nt16<<4)|ctx_idx, src/epialleleR.h:28-38
+ *   off[n+1]     int64 byte offsets, row x owns xm[off[x] .. off[x+1])
+ *   rname[n], strand[n] (1='+',2='-'), start[n] (1-based)   int32, R factor codes
+ *   pass[n]      R logical (int32; 0 = FALSE, anything else incl. NA = TRUE)
+ *
+ * The resident API (epi_batch_*) is the same computation on a batch that stays
+ * in HBM between calls -- the analogue of reusing a preprocessBam() object for
+ * several reports (R/preprocessBam.R:6-13).
+ *
+ * Every function returns 0 on success or an EPI_ERR_* code; epi_last_error()
+ * gives the message (thread-local).  HIP failures surface this way, never by
+ * abort().  There is NO CPU fallback: without the HIP runtime and a gfx950
+ * device every compute entry point fails with EPI_ERR_NODEVICE.
+ */
+#ifndef EPIHIP_H
+#define EPIHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPI_OK            0
+#define EPI_ERR_ARG       1   /* invalid argument                                   */
+#define EPI_ERR_HIP       2   /* HIP runtime error (message has the hipError name)  */
+#define EPI_ERR_UNSORTED  3   /* rows not sorted by (rname,start): "PRE-SORTED DATASET IS A REQUIREMENT", rcpp_cx_report.cpp:19 */
+#define EPI_ERR_NOMEM     4
+#define EPI_ERR_NODEVICE  5   /* no usable GPU                                      */
+#define EPI_ERR_STATE     6   /* call sequence error (e.g. fetch before report)     */
+
+const char *epi_last_error(void);
+int epi_version(void);
+
+/* Result tables: library-owned host arrays, release with the matching *_free.
+ * Factor levels are the reference's: strand {"+","-"}; context
+ * c("NA1","CHH","NA3","NA4","NA5","CHG","CG") i.e. 2=CHH 6=CHG 7=CG
+ * (rcpp_cx_report.cpp:146-155); rname levels are the caller's. */
+typedef struct {
+  int64_t nrow;
+  int32_t *rname, *strand, *pos, *context, *meth, *unmeth;
+} epi_cx_table;
+
+typedef struct {
+  int64_t nrow;
+  int32_t *rname, *strand, *pos, *context, *coverage;
+  double *length, *lmhl;
+} epi_mhl_table;
+
+void epi_cx_table_free(epi_cx_table *t);
+void epi_mhl_table_free(epi_mhl_table *t);
+
+/* ---- drop-in entry points (host pointers in, host results out) ---------- */
+
+int epi_threshold_reads(const uint8_t *xm, const int64_t *off, int64_t n,
+                        const char *ctx_meth, const char *ctx_unmeth,
+                        const char *ooctx_meth, const char *ooctx_unmeth,
+                        uint32_t min_n_ctx, double min_ctx_meth_frac,
+                        double max_ooctx_meth_frac, int32_t *pass_out /* [n] */);
+
+int epi_get_xm_beta(const uint8_t *xm, const int64_t *off, int64_t n,
+                    const char *ctx_meth, const char *ctx_unmeth,
+                    double *beta_out /* [n] */);
+
+int epi_cx_report(const uint8_t *xm, const int64_t *off, const int32_t *rname,
+                  const int32_t *strand, const int32_t *start,
+                  const int32_t *pass /* may be NULL = all TRUE */, int64_t n,
+                  const char *ctx, epi_cx_table *out);
+
+int epi_mhl_report(const uint8_t *xm, const int64_t *off, const int32_t *rname,
+                   const int32_t *strand, const int32_t *start, int64_t n,
+                   const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac,
+                   epi_mhl_table *out);
+
+/* ---- resident API -------------------------------------------------------- */
+
+typedef struct epi_engine epi_engine;   /* one per GPU: device id, streams, pinned staging */
+typedef struct epi_batch epi_batch;     /* templates resident in HBM + reusable workspace  */
+
+int epi_engine_create(int device, epi_engine **out);
+void epi_engine_destroy(epi_engine *e);
+int epi_engine_device(const epi_engine *e);
+
+/* Host SoA -> HBM through two pinned staging buffers and hipMemcpyAsync
+ * (double-buffered).  The batch owns its device memory. */
+int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off,
+                     const int32_t *rname, const int32_t *strand, const int32_t *start,
+                     int64_t n, epi_batch **out);
+
+/* Zero-copy: the caller (e.g. a torch tensor) owns the device buffers and
+ * keeps them alive.  d_xm must be 16-byte aligned and xm_capacity (bytes
+ * allocated) >= off[n] rounded up to 16.  nbytes = off[n]. */
+int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int64_t nbytes,
+                    const int64_t *d_off, const int32_t *d_rname, const int32_t *d_strand,
+                    const int32_t *d_start, int64_t n, epi_batch **out);
+void epi_batch_free(epi_batch *b);
+int64_t epi_batch_nrows(const epi_batch *b);
+
+/* `stream` is a hipStream_t (NULL = the engine's own stream).  The *_dev
+ * functions are asynchronous on that stream unless noted. */
+int epi_batch_threshold_reads_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth,
+                                  const char *ooctx_meth, const char *ooctx_unmeth,
+                                  uint32_t min_n_ctx, double min_ctx_meth_frac,
+                                  double max_ooctx_meth_frac, int32_t *d_pass_out, void *stream);
+int epi_batch_get_xm_beta_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth,
+                              double *d_beta_out, void *stream);
+
+/* CX report in two steps so the caller can allocate the output columns:
+ *  1) compute: tile index, LDS-histogram tile kernel, majority rule, ordered
+ *     row offsets.  Synchronises `stream` (row count comes back to the host).
+ *  2) fetch: gathers the rows, in reference order, into six int32 columns of
+ *     length nrow in device (fetch_dev, async) or host (fetch_host) memory. */
+int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass /* NULL = all TRUE */,
+                            const char *ctx, void *stream, int64_t *nrow_out);
+int epi_batch_cx_fetch_dev(epi_batch *b, int32_t *const d_cols[6], void *stream);
+int epi_batch_cx_fetch_host(epi_batch *b, int32_t *const h_cols[6], void *stream);
+
+int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin,
+                             double max_ooctx_meth_frac, void *stream, int64_t *nrow_out);
+int epi_batch_mhl_fetch_dev(epi_batch *b, int32_t *const d_icols[5], double *const d_dcols[2], void *stream);
+int epi_batch_mhl_fetch_host(epi_batch *b, int32_t *const h_icols[5], double *const h_dcols[2], void *stream);
+
+/* ---- multi-GPU (row-range shards; see DESIGN.md "Multi-GPU") -------------
+ * Tiles are cut on an absolute position grid (epi_tile_positions() wide), so
+ * ranks agree on tile boundaries.  A rank (a) reports the range of tile keys
+ * its rows touch, (b) is told which keys are shared with other ranks; shared
+ * tiles are accumulated into a dense counter slab instead of being emitted,
+ * (c) the caller sum-reduces the slabs across ranks (RCCL all-reduce), and
+ * (d) the owning rank emits them.  key = ((int64)rname << 32) | biased tile. */
+int epi_tile_positions(void);
+int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int64_t *last_key);
+int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned,
+                            int32_t nshared, int32_t *d_slab /* [nshared][16][T] int32, zeroed by caller */);
+/* With shared tiles set, epi_batch_cx_report_dev stops after accumulation
+ * (nrow_out = 0); all-reduce the slab, then finish: */
+int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int64_t *nrow_out);
+
+/* ---- synthetic input (bench/tests; DESIGN.md "Synthetic workload") ------- */
+typedef struct {
+  uint64_t seed;
+  int64_t n_total;        /* rows of the whole (all-ranks) stream              */
+  int64_t row_first;      /* first global row generated by this call           */
+  int64_t n;              /* rows generated by this call                       */
+  int32_t read_len;       /* bytes per template                                */
+  int32_t n_chr;
+  int32_t depth;          /* genome length per chromosome = rows*read_len/depth */
+  int32_t gap_from, gap_len; /* bytes [gap_from, gap_from+gap_len) are 0xFB filler (0 = none) */
+} epi_synth_params;
+int epi_synth_generate_dev(const epi_synth_params *p, uint8_t *d_xm, int64_t *d_off,
+                           int32_t *d_rname, int32_t *d_strand, int32_t *d_start, void *stream);
+
+/* ---- profiling hooks (HIP events around the dominant kernels) ------------ */
+void epi_prof_enable(int on);
+/* name: "cx_tiles", "threshold", "mhl_tiles", ...; returns accumulated ms and launch count since reset */
+int epi_prof_get(const char *name, double *ms_total, int64_t *launches);
+void epi_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPIHIP_H */

@@ -1,0 +1,99 @@
+"""BASELINE-size checks through size-independent properties (the oracle cannot run
+10 M reads in test time): determinism, strict (rname,pos,strand) order, and exact
+agreement with the oracle on windows of the genome cut out of the full-size input."""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _window_rows(bam, lo, hi):
+    """Host copy of rows [lo,hi) of a device-resident batch."""
+    d = bam.dev
+    off = d["off"][lo:hi + 1].cpu().numpy()
+    xm = d["xm"][int(off[0]):int(off[-1])].cpu().numpy()
+    return {"xm": xm, "off": off - off[0], "rname": d["rname"][lo:hi].cpu().numpy(),
+            "strand": d["strand"][lo:hi].cpu().numpy(), "start": d["start"][lo:hi].cpu().numpy()}
+
+
+def _check_windows(rep, bam, n, oracle_fn, float_cols=()):
+    key = rep["rname"].astype(np.int64) * (1 << 33) + rep["pos"].astype(np.int64) * 2 + (rep["strand"] - 1)
+    assert np.all(np.diff(key) > 0)                     # reference row order, no duplicates
+    L = 300
+    for lo in (0, n // 3 + 17, n - 20000):              # includes both ends and a chromosome interior
+        hi = lo + 20000
+        w = _window_rows(bam, lo, hi)
+        want = oracle_fn(w)
+        # rows of the window are complete only where no read outside [lo,hi) can reach: trim one read length
+        r0 = int(w["rname"][0])
+        p_lo = int(w["start"][0]) + L if lo > 0 else -1
+        r1 = int(w["rname"][-1])
+        p_hi = int(w["start"][-1]) - 1 if hi < n else 2 ** 31
+        def inner(t):
+            k = (t["rname"].astype(np.int64) << 32) + t["pos"]
+            return (k >= ((r0 << 32) + p_lo)) & (k <= ((r1 << 32) + p_hi))
+        mw = inner(want)
+        mg = inner(rep)
+        assert mw.sum() > 1000
+        for c in want:
+            a, b = rep[c][mg], want[c][mw]
+            assert a.shape == b.shape, c
+            if c in float_cols:
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), c
+            else:
+                assert np.array_equal(a, b), c
+
+
+def test_config2_cytosine_report_10M():
+    """BASELINE config 2: 10 M PE150 templates, generateCytosineReport on one MI355X."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 10_000_000
+    bam = synth.generate_device(n_total=n, read_len=300)
+    c = H.CONTEXT_TO_BASES["CG"]
+    rep = ea.generateCytosineReport(bam, threshold_reads=True)
+    rep2 = ea.generateCytosineReport(bam, threshold_reads=True)
+    for k in rep:
+        assert np.array_equal(rep[k], rep2[k])          # idempotent / deterministic
+    assert 5_000_000 < rep.nrow < 9_000_000
+    def oracle_fn(w):
+        p = orc.threshold_reads(w["xm"], w["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+        return orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], p, "Z")
+    _check_windows(rep, bam, n, oracle_fn)
+    cx = ea.generateCytosineReport(bam, threshold_reads=False, report_context="CX")
+    _check_windows(cx, bam, n, lambda w: orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], None, "ZXH"))
+    bam.close()
+
+
+def test_config4_mhl_report_scaled():
+    """BASELINE config 4 shape (generateMhlReport on PE150), at 5 M templates to bound test time."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 5_000_000
+    bam = synth.generate_device(n_total=n, read_len=300, seed=7)
+    rep = ea.generateMhlReport(bam)
+    _check_windows(rep, bam, n, lambda w: orc.mhl_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], "Zz", 0, 0, 0.1),
+                   float_cols=("length", "lmhl"))
+    bam.close()
+
+
+def test_config5_long_reads_scaled():
+    """BASELINE config 5 shape: 10 kb templates (one read per wavefront group), 100 k templates."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 100_000
+    bam = synth.generate_device(n_total=n, read_len=10000, seed=11)
+    rep = ea.generateCytosineReport(bam, threshold_reads=False)
+    key = rep["rname"].astype(np.int64) * (1 << 33) + rep["pos"].astype(np.int64) * 2 + (rep["strand"] - 1)
+    assert np.all(np.diff(key) > 0)
+    w = _window_rows(bam, 0, 3000)
+    want = orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], None, "Z")
+    lim = int(w["start"][-1]) - 1
+    mw = want["pos"] <= lim
+    mg = (rep["rname"] == 1) & (rep["pos"] <= lim)
+    for c in want:
+        assert np.array_equal(rep[c][mg], want[c][mw]), c
+    bam.close()

@@ -1,0 +1,277 @@
+"""Parity tests proper: the HIP engine (through the C ABI of libepihip.so) against
+the CPU oracle, bit-exact for every integer column and for the float64 columns
+(per-read beta, lMHL length/lmhl are compared bitwise; the stated tolerance is 0).
+Run on an MI355X with `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+import synth_np
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C2B = H.CONTEXT_TO_BASES
+ALL_CTX = ("CG", "CHG", "CHH", "CxG", "CX")
+
+
+@pytest.fixture(scope="module")
+def ea():
+    import epialleler_amd
+    return epialleler_amd
+
+
+def pb(ea, t, levels=None):
+    return ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"], levels or t.get("levels"))
+
+
+def o_thr(t, ctx="CG", min_n=2, min_beta=0.5, max_oo=0.1):
+    c = C2B[ctx]
+    return orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"],
+                               min_n, min_beta, max_oo)
+
+
+def check_all(ea, t, pass_variants=True, mhl=True, contexts=ALL_CTX):
+    """threshold + beta + cx + mhl on one template set against the oracle."""
+    bam = pb(ea, t)
+    try:
+        for ctx in contexts:
+            c = C2B[ctx]
+            got = ea.rcpp_threshold_reads(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+            want = o_thr(t, ctx)
+            assert np.array_equal(got.astype(np.int32), want), ("threshold", ctx)
+            gb = ea.rcpp_get_xm_beta(bam, c["ctx_meth"], c["ctx_unmeth"])
+            wb = orc.get_xm_beta(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"])
+            assert np.array_equal(gb.view(np.uint64), wb.view(np.uint64)), ("beta", ctx)     # tolerance 0 (<= 1e-6 required)
+            passes = [None]
+            if pass_variants:
+                passes.append(want)
+            for p in passes:
+                got = ea.rcpp_cx_report(bam, p, c["ctx_meth"])
+                want_r = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, c["ctx_meth"])
+                H.assert_reports_equal(dict(got), want_r)
+            if mhl:
+                for hmax, hmin, moo in ((0, 0, 0.1), (1, 0, 0.1), (3, 2, 1.0)):
+                    got = ea.rcpp_mhl_report(bam, c["ctx_meth"] + c["ctx_unmeth"], hmax, hmin, moo)
+                    want_m = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"],
+                                            c["ctx_meth"] + c["ctx_unmeth"], hmax, hmin, moo)
+                    H.assert_reports_equal(dict(got), want_m, float_cols=("length", "lmhl"))
+    finally:
+        bam.close()
+
+
+# ---- reference fixtures ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,kw", [
+    ("amplicon010meth.bam", {}),                      # BASELINE config 1
+    ("amplicon000meth.bam", {}),
+    ("amplicon100meth.bam", {}),
+    ("capture.bam", {}),
+    ("capture.bam", dict(min_mapq=30, min_baseq=20)),
+    ("capture.bam", dict(trim=3)),
+    ("dragen-se-unsort-xg-xm.bam", {}),
+    ("dragen-pe-namesort-xg-xm.bam", {}),
+])
+def test_fixture_bams(ea, name, kw):
+    t = H.bam(name, **kw)
+    check_all(ea, t)
+
+
+def test_capture_golden_numbers_through_gpu(ea):
+    # the reference's own known-answer values, straight from the GPU path
+    b = H.bam("capture.bam")
+    bam = pb(ea, b)
+    cg = ea.generateCytosineReport(bam)
+    cx = ea.generateCytosineReport(bam, threshold_reads=False, report_context="CX")
+    ev = lambda pre: H.expected_values("generateCytosineReport", pre)
+    assert [cg.nrow, 6] == ev("dim(cg.report)") and [cx.nrow, 6] == ev("dim(cx.report)")
+    assert [int(cg["meth"].sum())] == ev("sum(cg.report$meth)") and [int(cg["unmeth"].sum())] == ev("sum(cg.report$unmeth)")
+    assert [int(cx["meth"].sum())] == ev("sum(cx.report$meth)") and [int(cx["unmeth"].sum())] == ev("sum(cx.report$unmeth)")
+    m = ea.generateMhlReport(bam)
+    assert int(m["coverage"].sum()) == 20219
+    np.testing.assert_allclose([m["length"].sum(), m["lmhl"].sum()], [229119.960, 2666.456], rtol=2e-7)
+    m1 = ea.generateMhlReport(bam, max_haplotype_window=1)
+    cgu = ea.generateCytosineReport(bam, threshold_reads=False)
+    assert np.array_equal(m1["lmhl"], cgu["meth"] / (cgu["meth"] + cgu["unmeth"]))
+    assert cx.levels["context"][6] == "CG" and cx.levels["strand"] == ("+", "-") and cx.levels["rname"] == tuple(b["levels"])
+
+
+# ---- toy / edge cases ----------------------------------------------------------------------------
+
+def test_toys(ea):
+    check_all(ea, H.templates_from_xm(["ZZZzzZZZ", "ZZzzzzZZ"] * 3, [1, 2, 3, 4, 5, 6], [1, 2] * 3))
+    check_all(ea, H.templates_from_xm(["zZZZ"], [1], [1]))
+    check_all(ea, H.templates_from_xm(["Z.hZz", "Z.hZz", "..hZz"], [1, 1, 1], [1, 1, 1]))
+    check_all(ea, H.templates_from_xm(["Zz", "xz"], [1, 1], [1, 1]))
+    rng = np.random.default_rng(3)
+    xms = ["Z" * 10] + ["".join(rng.permutation(list("Zzzzzzzzzz"))) for _ in range(999)]
+    check_all(ea, H.templates_from_xm(xms, [1] * 1000, [1] * 1000))
+
+
+def test_empty_and_degenerate(ea):
+    empty = {"xm": np.zeros(0, np.uint8), "off": np.zeros(1, np.int64), "rname": np.zeros(0, np.int32),
+             "strand": np.zeros(0, np.int32), "start": np.zeros(0, np.int32)}
+    bam = pb(ea, empty)
+    assert ea.rcpp_threshold_reads(bam, "Z", "z", "XH", "xh", 2, 0.5, 0.1).size == 0
+    assert ea.rcpp_get_xm_beta(bam, "Z", "z").size == 0
+    assert ea.rcpp_cx_report(bam, None, "Z").nrow == 0
+    assert ea.rcpp_mhl_report(bam, "Zz", 0, 0, 0.1).nrow == 0
+    # rows of length zero, rows of only filler, a single byte
+    t = H.templates_from_xm(["", "--", "z", "", "Z-z", ""], [5, 5, 6, 7, 7, 9], [1, 2, 1, 2, 1, 1])
+    check_all(ea, t)
+    # everything is '.' (no rows at all) and everything is filler
+    check_all(ea, H.templates_from_xm(["....", "...."], [1, 3], [1, 2]))
+    check_all(ea, H.templates_from_xm(["++--", "-+-+"], [1, 3], [1, 2]))
+
+
+def test_ragged_random(ea):
+    rng = np.random.default_rng(11)
+    for n, mx, span in ((1, 50, 100), (7, 40, 60), (300, 400, 3000), (2000, 700, 20000), (500, 33, 400)):
+        check_all(ea, synth_np.random_templates(rng, n, 0, mx, 3, span))
+
+
+def test_tile_boundaries_and_large_positions(ea):
+    rng = np.random.default_rng(5)
+    # starts straddling multiples of the tile sizes (512/1024), near 2^31, and at position 0/1
+    for base in (1, 1000, 1024 * 7 - 150, 512 * 33 - 10, 2 ** 31 - 3000):
+        t = synth_np.random_templates(rng, 200, 1, 300, 2, 1500)
+        t["start"] = (t["start"].astype(np.int64) + base - 1).astype(np.int32)
+        check_all(ea, t, mhl=True, contexts=("CG", "CX"))
+
+
+def test_all_byte_values_and_odd_context_strings(ea):
+    # any nibble can reach the kernels (e.g. nibble 9 counts twice in coverage, lower-casing maps 4->'.')
+    rng = np.random.default_rng(17)
+    t = synth_np.random_templates(rng, 400, 0, 200, 2, 800, p_garbage=0.3)
+    check_all(ea, t)
+    bam = pb(ea, t)
+    # duplicated / unusual letters in context strings (the reference counts duplicates twice)
+    for cm, cu, om, ou in (("ZZ", "z", "XH", "xh"), ("Zz", "zZ", "", ""), ("U", "u", "Z", "z"), (".", "-", "+", "h")):
+        got = ea.rcpp_threshold_reads(bam, cm, cu, om, ou, 3, 0.4, 0.3)
+        want = orc.threshold_reads(t["xm"], t["off"], cm, cu, om, ou, 3, 0.4, 0.3)
+        assert np.array_equal(got.astype(np.int32), want)
+        gb = ea.rcpp_get_xm_beta(bam, cm, cu)
+        assert np.array_equal(gb.view(np.uint64), orc.get_xm_beta(t["xm"], t["off"], cm, cu).view(np.uint64))
+    for ctx in ("Z", "ZX", "H", "ZXHU", "z", ".", "Zz"):
+        for p in (None, (rng.random(400) < 0.5).astype(np.int32)):
+            H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, p, ctx)),
+                                   orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, ctx))
+    for ctx in ("Zz", "ZzXx", "Z", "HhUu", "Xx."):
+        H.assert_reports_equal(dict(ea.rcpp_mhl_report(bam, ctx, 0, 0, 0.1)),
+                               orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], ctx, 0, 0, 0.1),
+                               float_cols=("length", "lmhl"))
+    bam.close()
+
+
+def test_pass_na_counts_as_true(ea):
+    t = H.templates_from_xm(["Zz.", "zZ.", "ZZz"], [1, 2, 2], [1, 1, 2])
+    p = np.asarray([0, np.iinfo(np.int32).min, 1], np.int32)          # FALSE, NA, TRUE
+    bam = pb(ea, t)
+    H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, p, "Z")),
+                           orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, "Z"))
+
+
+def test_deep_pileup_and_many_rnames(ea):
+    rng = np.random.default_rng(23)
+    # amplicon-like: 6000 reads on the same ~400 positions (one tile gets everything)
+    t = synth_np.random_templates(rng, 6000, 100, 400, 1, 40)
+    check_all(ea, t, contexts=("CG", "CX"))
+    # many reference sequences with a handful of reads each, some rname ids unused
+    t = synth_np.random_templates(rng, 1500, 10, 200, 400, 3000)
+    t["rname"] = (t["rname"] * 3).astype(np.int32)
+    check_all(ea, t, contexts=("CG",))
+
+
+def test_long_reads(ea):
+    rng = np.random.default_rng(29)
+    t = synth_np.random_templates(rng, 40, 5000, 12000, 2, 30000, alphabet="......hhxzzZZZHXuU-")
+    check_all(ea, t, contexts=("CG", "CX"))
+    # test_generateMhlReport.R:102-122: two 10000-base reads
+    xms = ["".join(rng.choice(list("Zzzzzzzzzz"), 10000)) for _ in range(2)]
+    t = H.templates_from_xm(xms, [1, 1], [1, 1])
+    bam = pb(ea, t)
+    m = ea.rcpp_mhl_report(bam, "Zz", 1, 0, 0.1)
+    cg = ea.rcpp_cx_report(bam, None, "Z")
+    assert [int(m["coverage"].sum()), m["length"].sum()] == [20000, 100000000]
+    assert np.array_equal(m["lmhl"], cg["meth"] / (cg["meth"] + cg["unmeth"]))
+
+
+def test_unsorted_rows_are_rejected(ea):
+    t = H.templates_from_xm(["zz", "zz", "zz"], [1, 1, 1], [1, 1, 1])
+    t["start"] = np.asarray([1, 10, 2], np.int32)
+    bam = pb(ea, t)
+    with pytest.raises(ea.EpihipError) as ei:
+        ea.rcpp_cx_report(bam, None, "Z")
+    assert ei.value.code == 3
+    with pytest.raises(ea.EpihipError):
+        ea.rcpp_mhl_report(bam, "Zz", 0, 0, 0.1)
+    # per-read functions do not need sorted rows
+    assert ea.rcpp_threshold_reads(bam, "Z", "z", "", "", 0, 0.0, 1.0).size == 3
+    t["start"] = np.asarray([1, 2, 3], np.int32)
+    t["strand"] = np.asarray([1, 3, 1], np.int32)
+    with pytest.raises(ea.EpihipError):
+        ea.rcpp_cx_report(pb(ea, t), None, "Z")
+
+
+def test_match_arg_and_defaults(ea):
+    t = H.templates_from_xm(["Zz"], [1], [1])
+    with pytest.raises(ValueError):
+        ea.generateCytosineReport(pb(ea, t), threshold_context="CpG")
+    r = ea.generateCytosineReport(pb(ea, t), threshold_reads=False)
+    assert r.nrow == 2 and list(r.keys()) == ["rname", "strand", "pos", "context", "meth", "unmeth"]
+
+
+# ---- synthetic workload (BASELINE configs 2-5 shape) -----------------------------------------------
+
+def test_synth_matches_numpy_mirror(ea):
+    import torch
+    from epialleler_amd import synth
+    for kw in (dict(n_total=3000, read_len=300), dict(n_total=1000, read_len=97, n_chr=3, depth=7, gap_from=40, gap_len=11),
+               dict(n_total=5000, read_len=300, row_first=1234, n=2000)):
+        bam = synth.generate_device(**kw)
+        ref = synth_np.generate(**kw)
+        d = bam.dev
+        assert np.array_equal(d["xm"][:bam.nbytes].cpu().numpy(), ref["xm"])
+        for k in ("off", "rname", "strand", "start"):
+            assert np.array_equal(d[k].cpu().numpy(), ref[k]), k
+        bam.close()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kw", [dict(n_total=20000, read_len=300), dict(n_total=6000, read_len=300, gap_from=150, gap_len=50),
+                                dict(n_total=300, read_len=10000, n_chr=2)])
+def test_synth_medium_parity(ea, kw):
+    t = synth_np.generate(**kw)
+    check_all(ea, t, contexts=("CG", "CX"))
+
+
+def test_host_drop_in_entry_points(ea):
+    """The four host-pointer functions an R shim binds, called as C."""
+    from epialleler_amd import _lib
+    lib = _lib.load()
+    t = H.bam("amplicon010meth.bam")
+    n = t["off"].size - 1
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    out = np.zeros(n, np.int32)
+    _lib.check(lib.epi_threshold_reads(vp(t["xm"]), vp(t["off"]), n, b"Z", b"z", b"XH", b"xh", 2, 0.5, 0.1, vp(out)))
+    assert np.array_equal(out, o_thr(t)) and int(out.sum()) == 48
+    beta = np.zeros(n, np.float64)
+    _lib.check(lib.epi_get_xm_beta(vp(t["xm"]), vp(t["off"]), n, b"Z", b"z", vp(beta)))
+    assert np.array_equal(beta, orc.get_xm_beta(t["xm"], t["off"], "Z", "z"))
+    tab = _lib.CxTable()
+    _lib.check(lib.epi_cx_report(vp(t["xm"]), vp(t["off"]), vp(t["rname"]), vp(t["strand"]), vp(t["start"]), vp(out), n, b"Z", C.byref(tab)))
+    got = {k: np.ctypeslib.as_array(getattr(tab, k), shape=(tab.nrow,)).copy() for k in ("rname", "strand", "pos", "context", "meth", "unmeth")}
+    lib.epi_cx_table_free(C.byref(tab))
+    H.assert_reports_equal(got, orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], out, "Z"))
+    assert [got["pos"].size, int(got["meth"].sum()), int(got["unmeth"].sum())] == [478, 632, 6449]     # BASELINE config 1
+    mt = _lib.MhlTable()
+    _lib.check(lib.epi_mhl_report(vp(t["xm"]), vp(t["off"]), vp(t["rname"]), vp(t["strand"]), vp(t["start"]), n, b"Zz", 0, 0, 0.1, C.byref(mt)))
+    gm = {k: np.ctypeslib.as_array(getattr(mt, k), shape=(mt.nrow,)).copy() for k in ("rname", "strand", "pos", "context", "coverage", "length", "lmhl")}
+    lib.epi_mhl_table_free(C.byref(mt))
+    H.assert_reports_equal(gm, orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", 0, 0, 0.1),
+                           float_cols=("length", "lmhl"))
+    # error path: NULL offsets
+    assert lib.epi_threshold_reads(None, None, 1, b"Z", b"z", b"", b"", 0, 0.0, 0.0, vp(out)) == 1
+    assert b"bad arguments" in lib.epi_last_error()

@@ -1,0 +1,92 @@
+"""CPU-only checks of the host layer and the C-ABI library: the context table,
+argument handling, that libepihip.so loads and exports every symbol declared in
+include/epihip.h, and that the product path fails loudly without a GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from epialleler_amd import _lib
+    _lib.build()                      # hipcc cross-compiles for gfx950 without a GPU
+    return _lib.load()
+
+
+def test_context_table_matches_reference():
+    import epialleler_amd as ea
+    assert ea.CONTEXT_TO_BASES == H.CONTEXT_TO_BASES
+    assert ea.CONTEXT_LEVELS[1] == "CHH" and ea.CONTEXT_LEVELS[5] == "CHG" and ea.CONTEXT_LEVELS[6] == "CG"
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from epialleler_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "epihip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(epi_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (epi_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.epi_version() >= 100 and lib.epi_tile_positions() == 1024
+
+
+def test_no_oracle_in_product_path():
+    # the product must never import or link the CPU oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "epialleler_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.lower().replace("no cpu", ""), os.path.join(dirpath, f)
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import epialleler_amd as ea
+    t = H.templates_from_xm(["Zz"], [1], [1])
+    bam = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"])
+    with pytest.raises(ea.EpihipError) as ei:
+        ea.rcpp_cx_report(bam, None, "Z")
+    assert ei.value.code == 5 and "no CPU fallback" in str(ei.value)
+    # the host-pointer entry points fail the same way
+    import ctypes as C
+    out = np.zeros(1, np.int32)
+    rc = lib.epi_threshold_reads(C.c_void_p(t["xm"].ctypes.data), C.c_void_p(t["off"].ctypes.data), 1,
+                                 b"Z", b"z", b"", b"", 0, 0.0, 1.0, C.c_void_p(out.ctypes.data))
+    assert rc == 5
+
+
+def test_processed_bam_validation():
+    import epialleler_amd as ea
+    t = H.templates_from_xm(["Zz", "zz"], [1, 2], [1, 2])
+    with pytest.raises(ValueError):
+        ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"][:1], t["strand"], t["start"])
+    with pytest.raises(ValueError):
+        ea.ProcessedBam.from_arrays(t["xm"][:-1], t["off"], t["rname"], t["strand"], t["start"])
+    b = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"], levels=["chr1"])
+    assert b.n == 2 and b.nbytes == 4 and ea.preprocessBam(b) is b
+    with pytest.raises(NotImplementedError):
+        ea.preprocessBam("some.bam")
+
+
+def test_write_report_tsv(tmp_path):
+    import epialleler_amd as ea
+    rep = ea.Report({"rname": np.asarray([1, 1], np.int32), "strand": np.asarray([1, 2], np.int32),
+                     "pos": np.asarray([10, 11], np.int32), "context": np.asarray([7, 2], np.int32),
+                     "meth": np.asarray([3, 0], np.int32), "unmeth": np.asarray([1, 5], np.int32)}, ["chr1"])
+    p = tmp_path / "r.tsv"
+    ea.writeReport(rep, str(p))
+    assert p.read_text() == "rname\tstrand\tpos\tcontext\tmeth\tunmeth\nchr1\t+\t10\tCG\t3\t1\nchr1\t-\t11\tCHH\t0\t5\n"
+    import gzip
+    ea.writeReport(rep, str(tmp_path / "r.tsv.gz"), gzip=True)
+    assert gzip.open(tmp_path / "r.tsv.gz", "rt").read() == p.read_text()
