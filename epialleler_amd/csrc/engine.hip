@@ -41,8 +41,11 @@ void DevBuf::release() {
   cap = 0;
 }
 
+// A NULL `stream` is the HIP null stream (what torch's default stream is), NOT the engine's
+// private stream: work must stay ordered with whatever the caller queued before.
 hipStream_t pick_stream(epi_batch *b, void *stream) {
-  return stream ? reinterpret_cast<hipStream_t>(stream) : b->eng->stream;
+  (void)b;
+  return reinterpret_cast<hipStream_t>(stream);
 }
 
 int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst) {

@@ -115,8 +115,9 @@ int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int
 void epi_batch_free(epi_batch *b);
 int64_t epi_batch_nrows(const epi_batch *b);
 
-/* `stream` is a hipStream_t (NULL = the engine's own stream).  The *_dev
- * functions are asynchronous on that stream unless noted. */
+/* `stream` is a hipStream_t; NULL is the HIP null stream (e.g. torch's default
+ * stream), so the call is ordered after whatever the caller queued there.  The
+ * *_dev functions are asynchronous on that stream unless noted. */
 int epi_batch_threshold_reads_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth,
                                   const char *ooctx_meth, const char *ooctx_unmeth,
                                   uint32_t min_n_ctx, double min_ctx_meth_frac,
