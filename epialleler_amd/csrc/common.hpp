@@ -110,8 +110,8 @@ int scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_
                        DevBuf &tmp, hipStream_t s);
 
 // tile index (tiles.hip)
-int build_row_stats(epi_batch *b, hipStream_t s, RowStats *h_stats);
-int build_tiles(epi_batch *b, hipStream_t s, int32_t max_len, int32_t tile_positions, int32_t *ntiles_out);
+// row statistics (validated: errors for bad offsets/strands/unsorted rows) + tile table; one host sync
+int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out);
 
 // profiling
 void prof_begin(const char *name, hipStream_t s);

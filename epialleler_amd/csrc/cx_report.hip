@@ -7,12 +7,12 @@
 // the result: the output is the per-(rname,pos,strand) counter table pushed
 // through the rule, in (rname, pos, '+' before '-') order.
 //
-// Here a workgroup owns one tile of kTile consecutive positions (tiles.hip).
-// Its candidate rows are a contiguous row range; each wavefront takes rows
-// from it, streams the slice of the row that falls inside the tile with
-// coalesced dword loads and adds every base into u32 counters in LDS
-// ([strand][8 counters][kTile], 64 KiB) with ds_add_u32 -- consecutive lanes
-// hit consecutive banks, so the histogram is conflict-free by construction.
+// Here a workgroup owns one tile of T (default 1024) consecutive positions (tiles.hip).
+// Its candidate rows are a contiguous row range; a group of G lanes takes a
+// row, streams the slice of the row that falls inside the tile with coalesced
+// dword loads (several in flight per lane) and adds every base into u32
+// counters in LDS ([strand][8 counters][T], 64 KiB) with ds_add_u32; lanes of a
+// group walk consecutive positions, so their atomics spread over the banks.
 // Only eight counters per (pos,strand) are ever read by the rule: '.', H, h,
 // X, x, Z, z and "everything else that counts toward coverage" (U/u and any
 // other nibble; nibble 9 counts twice because the reference's coverage slot is
@@ -28,20 +28,16 @@
 namespace epi {
 
 constexpr int CX_WG = 512;                    // threads per tile workgroup (8 wavefronts)
-constexpr int CX_PPT = kTile / CX_WG;         // positions per thread in the emit phase
-static_assert(kTile % CX_WG == 0 && (CX_PPT == 1 || CX_PPT == 2 || CX_PPT == 4), "emit phase layout");
+constexpr int CX_UN = 5;                      // dword loads a lane keeps in flight per row (cx_accumulate is written for 5)
 
-// nibble -> counter slot (4 bits per code): see enum in common.hpp
-//   code:  0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15
-//   slot:  1 1 2 1 1 1 4 6 1 1  3  8  0  1  5  7
-constexpr uint64_t kSlotMap = 0x7510831164111211ull;
-
-__device__ __forceinline__ int readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
-  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), lane);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
+// nibble -> (counter slot, increment) as a 16-entry byte LUT for v_perm_b32: bits 0-2 = slot (see
+// enum in common.hpp), bits 4-5 = increment.
+//   code:     0    1    2    3    4    5    6    7 |   8    9   10   11 |  12   13   14   15
+//   byte:  0x11 0x11 0x12 0x11 0x11 0x11 0x14 0x16 | 0x11 0x21 0x13 0x00 | 0x10 0x11 0x15 0x17
+// increment 0 = skipped ('+'/'-' and filler, rcpp_cx_report.cpp:123: the atomic still issues but adds
+// nothing); 2 = nibble 9, which IS the reference's coverage slot and so counts twice (:126-127).
+constexpr uint32_t kLutLo0 = 0x11121111u, kLutLo1 = 0x16141111u, kLutHi0 = 0x00132111u, kLutHi1 = 0x17151110u;
+constexpr int kCxGuard = 4;               // dwords of LDS padding around the counters (see cx_add_dword)
 
 struct CxArgs {
   const uint8_t *xm;
@@ -53,57 +49,103 @@ struct CxArgs {
   uint32_t pool_cap;
   uint32_t *cursor;                       // rows handed out so far (may exceed pool_cap: overflow)
   uint32_t *tile_nrow, *tile_base;
-  int32_t *slab;                          // shared-tile counters [slot][16][kTile]
+  int32_t *slab;                          // shared-tile counters [slot][16][T]
 };
 
-// Adds the in-tile slice of the rows [row_lo,row_hi) into the LDS counters.
-__device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = CX_WG / 64;
-  const int rot = (lane >> 3) & 3;          // byte order rotation: lanes l, l+8, l+16, l+24 (same bank at
-                                            // a 4-dword stride) work on different bytes of their dword
-  for (int rbase = td.row_lo + wave * 64; rbase < td.row_hi; rbase += NW * 64) {
-    const int r = rbase + lane;
-    int i_lo = 0, i_hi = 0, pbase = 0, sflag = 0, lc = 0;
-    int64_t o = 0;
-    if (r < td.row_hi) {
-      const int64_t st = a.start[r];
-      o = a.off[r];
-      const int64_t len = a.off[r + 1] - o;
-      const int64_t rel = td.pos0 - st;                  // row index of the tile's first position
-      const int64_t lo = rel > 0 ? rel : 0;
-      const int64_t hi = len < rel + kTile ? len : rel + kTile;
-      if (hi > lo) { i_lo = (int)lo; i_hi = (int)hi; }
-      pbase = (int)(-rel);                               // LDS position of row byte 0 (may be negative)
-      sflag = a.strand[r] - 1;
-      lc = (a.pass && a.pass[r] == 0) ? 8 : 0;           // !pass -> lower-case, rcpp_cx_report.cpp:118
+struct RowSlice {                         // the part of one row that falls inside the tile, seen from one lane
+  const uint32_t *src;                    // this lane's first dword of the (dword-aligned) slice in xm
+  uint32_t *dst;                          // LDS cell of byte 0 of that dword in counter plane 0 of the row's strand
+  int nd;                                 // dwords in the slice (0 = nothing to do)
+  uint32_t lc4;                           // 0x08080808 when the read failed thresholding (lower-case, :118)
+  uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
+};
+
+template <int T, int G>
+__device__ __forceinline__ RowSlice cx_row_slice(const CxArgs &a, const Tile &td, int r, int sub, uint32_t *cnt) {
+  RowSlice m;
+  m.src = nullptr; m.dst = cnt; m.nd = 0; m.lc4 = 0; m.mask_first = ~0u; m.mask_last = ~0u;
+  if (r < td.row_hi) {
+    const int32_t st = a.start[r];
+    const int64_t o = a.off[r];
+    const int32_t len = (int32_t)((uint32_t)a.off[r + 1] - (uint32_t)o);   // < 2^31 (checked by k_row_stats)
+    const int32_t sd = a.strand[r];
+    const int32_t ps = a.pass ? a.pass[r] : 1;
+    // row index of the tile's first position; |rel| < Lmax + T for a candidate row
+    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)st);
+    const int32_t lo = rel > 0 ? rel : 0;
+    const int32_t hi = len < rel + T ? len : rel + T;
+    if (hi > lo) {
+      const int64_t b0 = o + lo;
+      const int32_t e_lo = (int32_t)b0 & 3;              // slice bytes are e in [e_lo, e_hi) from the aligned start
+      const int32_t e_hi = e_lo + (hi - lo);
+      m.nd = (e_hi + 3) >> 2;
+      m.src = reinterpret_cast<const uint32_t *>(a.xm + (b0 - e_lo)) + sub;
+      m.dst = cnt + (sd - 1) * 8 * T + (lo - rel - e_lo) + 4 * sub;
+      m.lc4 = ps == 0 ? 0x08080808u : 0u;
+      m.mask_first = sub == 0 ? 0xFFFFFFFFu << (8 * e_lo) : ~0u;
+      m.mask_last = 0xFFFFFFFFu >> (8 * (4 * m.nd - e_hi));
     }
-    const int nrows = td.row_hi - rbase < 64 ? td.row_hi - rbase : 64;
-    for (int j = 0; j < nrows; j++) {
-      const int jl = readlane_i32(i_lo, j), jh = readlane_i32(i_hi, j);
-      if (jl >= jh) continue;
-      const int64_t jo = readlane_i64(o, j);
-      const int jp = readlane_i32(pbase, j);
-      const uint32_t jlc = (uint32_t)readlane_i32(lc, j);
-      uint32_t *cb = cnt + readlane_i32(sflag, j) * (8 * kTile);
-      const int64_t b0 = jo + jl, b1 = jo + jh;          // byte range of the slice in xm
-      for (int64_t ad = (b0 & ~3LL) + 4 * lane; ad < b1; ad += 256) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(a.xm + ad);
+  }
+  return m;
+}
+
+// One dword (four bases) of a row into the LDS counters.  Every lane issues all four atomics: bytes
+// outside the slice and skipped codes are turned into "+0 on plane 0" by the masks, never branched
+// around.  A masked byte can sit up to 3 cells outside [0,T): the counters carry kCxGuard cells of
+// padding for that.  `rot` staggers the byte order so lanes l and l+8 (32 dwords apart) hit different banks.
+template <int T, int OFF, bool FIRST>
+__device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m, int rot8) {
+  const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
+  const uint32_t lo3 = c4 & 0x07070707u;
+  const uint32_t b3 = (c4 >> 3) & 0x01010101u;
+  const uint32_t hm = (b3 << 8) - b3;                    // 0xFF where code >= 8
+  uint32_t s4 = (__builtin_amdgcn_perm(kLutHi1, kLutHi0, lo3) & hm) |
+                (__builtin_amdgcn_perm(kLutLo1, kLutLo0, lo3) & ~hm);
+  uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
+  if (FIRST) vm &= m.mask_first;
+  s4 &= vm;
+  s4 = __builtin_amdgcn_alignbit(s4, s4, rot8);          // rotate right by rot bytes: byte q <- byte (q+rot)&3
+  uint32_t *base = m.dst + OFF;                          // OFF = 4 * (this dword's index - the lane's first index)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int bb = (q + rot) & 3;
-          const int64_t bad = ad + bb;
-          if (bad >= b0 && bad < b1) {
-            const uint32_t code = ((w >> (8 * bb)) & 15u) | jlc;
-            const uint32_t slot = (uint32_t)(kSlotMap >> (4 * code)) & 15u;
-            if (slot != SLOT_SKIP) {
-              const int p = jp + (int)(bad - jo);
-              atomicAdd(&cb[slot * kTile + p], code == 9u ? 2u : 1u);
-            }
-          }
-        }
-      }
+  for (int q = 0; q < 4; q++) {
+    const uint32_t plane = (s4 >> (8 * q)) & 7u;
+    const uint32_t inc = (s4 >> (8 * q + 4)) & 3u;
+    atomicAdd(base + plane * T + ((q + (rot8 >> 3)) & 3), inc);
+  }
+}
+
+// Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
+// (64/G rows per wavefront step); a lane keeps CX_UN dword loads of its row in flight and the next
+// step's row metadata is fetched before the current step's atomics are issued.
+template <int T, int G>
+__device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
+  constexpr int R = 64 / G;
+  constexpr int NW = CX_WG / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G;
+  const int rot8 = ((sub >> 3) & 3) * 8;
+  int r = td.row_lo + wave * R + grp;
+  RowSlice cur = cx_row_slice<T, G>(a, td, r, sub, cnt);
+  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
+    uint32_t w[CX_UN];
+#pragma unroll
+    for (int u = 0; u < CX_UN; u++) {
+      const int k = sub + u * G;
+      w[u] = k < cur.nd ? cur.src[u * G] : 0u;
     }
+    r += NW * R;
+    const RowSlice nxt = cx_row_slice<T, G>(a, td, r, sub, cnt);
+    if (sub < cur.nd) cx_add_dword<T, 0, true>(w[0], sub, cur, rot8);
+    if (sub + G < cur.nd) cx_add_dword<T, 4 * G, false>(w[1], sub + G, cur, rot8);
+    if (sub + 2 * G < cur.nd) cx_add_dword<T, 8 * G, false>(w[2], sub + 2 * G, cur, rot8);
+    if (sub + 3 * G < cur.nd) cx_add_dword<T, 12 * G, false>(w[3], sub + 3 * G, cur, rot8);
+    if (sub + 4 * G < cur.nd) cx_add_dword<T, 16 * G, false>(w[4], sub + 4 * G, cur, rot8);
+    for (int k = sub + CX_UN * G; k < cur.nd; k += G) {   // slices longer than CX_UN*G dwords (long reads, small G)
+      RowSlice t = cur;
+      t.dst = cur.dst + 4 * (k - sub);
+      cx_add_dword<T, 0, false>(cur.src[k - sub], k, t, rot8);
+    }
+    cur = nxt;
   }
 }
 
@@ -123,20 +165,23 @@ __device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, u
 }
 
 // Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
+template <int T>
 __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
+  constexpr int PPT = T / CX_WG;                          // consecutive positions per thread
+  static_assert(PPT == 1 || PPT == 2 || PPT == 4, "emit phase layout");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = CX_WG / 64;
-  const int p0 = threadIdx.x * CX_PPT;
-  uint32_t key[2 * CX_PPT], me[2 * CX_PPT], un[2 * CX_PPT];   // statically indexed (fully unrolled): stay in VGPRs
-  bool ok[2 * CX_PPT];
+  const int p0 = threadIdx.x * PPT;
+  uint32_t key[2 * PPT], me[2 * PPT], un[2 * PPT];       // statically indexed (fully unrolled): stay in VGPRs
+  bool ok[2 * PPT];
   int nr = 0;
 #pragma unroll
-  for (int q = 0; q < CX_PPT; q++) {
+  for (int q = 0; q < PPT; q++) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       uint32_t c[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * kTile + p0 + q];
+      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
       uint32_t m = 0, u = 0;
       const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
       ok[q * 2 + s] = ctx != 0;
@@ -171,7 +216,7 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
   if ((uint64_t)base + total <= a.pool_cap) {
     uint32_t w = base + ex;
 #pragma unroll
-    for (int i = 0; i < 2 * CX_PPT; i++) {
+    for (int i = 0; i < 2 * PPT; i++) {
       if (ok[i]) {
         a.pool_key[w] = key[i];
         a.pool_meth[w] = me[i];
@@ -182,41 +227,44 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
   }
 }
 
+template <int T, int G>
 __global__ __launch_bounds__(CX_WG) void k_cx_tiles(CxArgs a) {
-  __shared__ uint32_t cnt[kCxPlanes * kTile];
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[kCxPlanes * T + 2 * kCxGuard];
   __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = blockIdx.x;
-  uint4 *z = reinterpret_cast<uint4 *>(cnt);
-  for (int i = threadIdx.x; i < kCxPlanes * kTile / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const Tile td = a.tiles[tile];
-  cx_accumulate(a, td, cnt);
+  cx_accumulate<T, G>(a, td, cnt);
   __syncthreads();
   if (td.slot >= 0) {
     // shared with another rank (or split over several work items): hand the raw counters over
-    int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * kTile);
-    for (int i = threadIdx.x; i < kCxPlanes * kTile; i += CX_WG) {
+    int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * T);
+    for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) {
       const uint32_t v = cnt[i];
       if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
     }
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
-  cx_emit(a, tile, cnt, s_scan);
+  cx_emit<T>(a, tile, cnt, s_scan);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
+template <int T>
 __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned, int ntiles) {
-  __shared__ uint32_t cnt[kCxPlanes * kTile];
+  __shared__ uint32_t cnt[kCxPlanes * T];
   __shared__ uint32_t s_scan[CX_WG / 64 + 2];
   const int tile = blockIdx.x;
   if (tile >= ntiles) return;
   const Tile td = a.tiles[tile];
   if (td.slot < 0 || !owned[td.slot]) return;
-  const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * kTile);
-  for (int i = threadIdx.x; i < kCxPlanes * kTile; i += CX_WG) cnt[i] = (uint32_t)src[i];
+  const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * T);
+  for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
   __syncthreads();
-  cx_emit(a, tile, cnt, s_scan);
+  cx_emit<T>(a, tile, cnt, s_scan);
 }
 
 // Output row i -> its tile (binary search in the exclusive scan of tile row counts) -> decode.
@@ -245,6 +293,48 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
   o_unmeth[i] = (int32_t)pool_unmeth[src];
 }
 
+// lanes per row: enough that CX_UN dwords per lane cover the longest in-tile slice
+static int pick_cx_group(int32_t max_len, int T) {
+  const char *env = getenv("EPIHIP_CX_GROUP");
+  if (env) { int g = atoi(env); if (g == 8 || g == 16 || g == 32 || g == 64) return g; }
+  const int slice = (max_len < T ? max_len : T) + 3;
+  const int nd = (slice + 3) / 4;
+  int g = 8;
+  while (g < 64 && g * CX_UN < nd) g <<= 1;
+  return g;
+}
+
+int cx_tile_positions() {
+  static int t = 0;
+  if (!t) {
+    t = kTile;
+    if (const char *env = getenv("EPIHIP_CX_TILE")) { const int v = atoi(env); if (v == 512 || v == 1024 || v == 2048) t = v; }
+  }
+  return t;
+}
+
+template <int T>
+static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cx_tiles<T, 64>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
+  }
+}
+
+static void launch_cx_tiles(int T, int g, int nt, hipStream_t s, const CxArgs &a) {
+  if (T == 512) launch_cx_tiles_g<512>(g, nt, s, a);
+  else if (T == 2048) launch_cx_tiles_g<2048>(g, nt, s, a);
+  else launch_cx_tiles_g<1024>(g, nt, s, a);
+}
+
+static void launch_cx_emit_slab(int T, int nt, hipStream_t s, const CxArgs &a, const int32_t *owned) {
+  if (T == 512) hipLaunchKernelGGL((k_cx_emit_slab<512>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
+  else if (T == 2048) hipLaunchKernelGGL((k_cx_emit_slab<2048>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
+  else hipLaunchKernelGGL((k_cx_emit_slab<1024>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
+}
+
 static int ensure_pool(epi_batch *b, size_t rows) {
   if (rows <= b->pool_cap && b->pool_key.p) return EPI_OK;
   EPI_TRY(b->pool_key.ensure(rows * 4));
@@ -260,7 +350,7 @@ using namespace epi;
 
 extern "C" {
 
-int epi_tile_positions(void) { return kTile; }
+int epi_tile_positions(void) { return cx_tile_positions(); }
 
 int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx, void *stream, int64_t *nrow_out) {
   if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_dev: NULL argument");
@@ -272,20 +362,18 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   uint32_t ctx_mask = 0;                                   // rcpp_cx_report.cpp:88-91
   for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
 
+  const int T = cx_tile_positions();
   RowStats st;
-  EPI_TRY(build_row_stats(b, s, &st));
-  if (st.unsorted)
-    return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start); the reference requires a pre-sorted dataset "
-                                  "(src/rcpp_cx_report.cpp:19)");
   int32_t nt = 0;
-  EPI_TRY(build_tiles(b, s, st.max_len, kTile, &nt));
+  EPI_TRY(build_tiles(b, s, T, &st, &nt));
   b->last_ntiles = nt;
   if (nt == 0) { b->last_kind = 1; b->last_nrow = 0; return EPI_OK; }
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
-  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * (kTile / 4) + 65536));
+  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * (T / 4) + 65536));
+  const int grp = pick_cx_group(st.max_len, T);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
   CxArgs a;
@@ -299,7 +387,8 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   const int32_t nshared = (int32_t)b->shared_keys.size();
 
   // Shared tiles are emitted later (epi_batch_cx_finish_shared) into the same pool: keep room for them.
-  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * kTile : 0;
+  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * T : 0;
+  uint32_t used_total[2] = {0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_meth = b->pool_a.as<uint32_t>();
@@ -307,26 +396,22 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
     EPI_HIP(hipMemsetAsync(cursor, 0, 8, s));
     prof_begin("cx_tiles", s);
-    hipLaunchKernelGGL(k_cx_tiles, dim3((unsigned)nt), dim3(CX_WG), 0, s, a);
+    launch_cx_tiles(T, grp, nt, s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
-    uint32_t used = 0;
-    EPI_TRY(read_scalars(b, s, cursor, 4, &used));
-    if ((size_t)used + headroom <= a.pool_cap) break;
+    // row offsets of the tiles are queued right away; {rows handed out, total rows} come back in one sync
+    EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+    EPI_TRY(read_scalars(b, s, cursor, 8, used_total));
+    if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_pool(b, (size_t)used + (used >> 4) + 1024 + headroom));   // exact need is known now: rerun once
+    EPI_TRY(ensure_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once
     if (nshared > 0)   // the rerun adds into the slab again
-      EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * kTile * 4, s));
+      EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * T * 4, s));
   }
   if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
-
-  uint32_t *d_total = b->misc.as<uint32_t>() + 2;
-  EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
-  uint32_t total = 0;
-  EPI_TRY(read_scalars(b, s, d_total, 4, &total));
   b->last_kind = 1;
-  b->last_nrow = total;
-  *nrow_out = total;
+  b->last_nrow = used_total[1];
+  *nrow_out = used_total[1];
   return EPI_OK;
 }
 
@@ -353,7 +438,7 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   a.pool_meth = b->pool_a.as<uint32_t>();
   a.pool_unmeth = b->pool_b.as<uint32_t>();
   a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
-  hipLaunchKernelGGL(k_cx_emit_slab, dim3((unsigned)nt), dim3(CX_WG), 0, s, a, b->d_shared_owned.as<int32_t>(), nt);
+  launch_cx_emit_slab(cx_tile_positions(), nt, s, a, b->d_shared_owned.as<int32_t>());
   EPI_HIP(hipGetLastError());
   {
     uint32_t used = 0;   // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
@@ -394,16 +479,15 @@ int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   *first_key = 0; *last_key = -1;              // empty range
+  const int T = cx_tile_positions();
   RowStats st;
-  EPI_TRY(build_row_stats(b, s, &st));
-  if (st.unsorted) return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start)");
   int32_t nt = 0;
-  EPI_TRY(build_tiles(b, s, st.max_len, kTile, &nt));
+  EPI_TRY(build_tiles(b, s, T, &st, &nt));
   if (nt == 0) return EPI_OK;
   Tile t0, t1;
   EPI_TRY(read_scalars(b, s, b->tiles.as<Tile>(), sizeof(Tile), &t0));
   EPI_TRY(read_scalars(b, s, b->tiles.as<Tile>() + (nt - 1), sizeof(Tile), &t1));
-  auto key = [](const Tile &t) { return ((int64_t)t.rname << 32) | (int64_t)(uint32_t)((t.pos0 + kPosBias) / kTile); };
+  auto key = [T](const Tile &t) { return ((int64_t)t.rname << 32) | (int64_t)(uint32_t)((t.pos0 + kPosBias) / T); };
   *first_key = key(t0);
   *last_key = key(t1);
   return EPI_OK;

@@ -415,11 +415,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   const uint32_t H = hmax > 0 ? (hmax < 65536 ? (uint32_t)hmax : 65536u) : 65536u;   // :112
 
   RowStats st;
-  EPI_TRY(build_row_stats(b, s, &st));
-  if (st.unsorted)
-    return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start); the reference requires a pre-sorted dataset");
   int32_t nt = 0;
-  EPI_TRY(build_tiles(b, s, st.max_len, kMhlTile, &nt));
+  EPI_TRY(build_tiles(b, s, kMhlTile, &st, &nt));
   b->last_ntiles = nt;
   if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; return EPI_OK; }
 
@@ -459,6 +456,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.cursor = cursor;
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
+  uint32_t used_total[2] = {0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_cov = b->pool_a.as<uint32_t>();
@@ -470,19 +468,15 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     hipLaunchKernelGGL(k_mhl_tiles, dim3((unsigned)nt), dim3(MHL_WG), 0, s, a);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
-    uint32_t used = 0;
-    EPI_TRY(read_scalars(b, s, cursor, 4, &used));
-    if (used <= a.pool_cap) break;
+    EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+    EPI_TRY(read_scalars(b, s, cursor, 8, used_total));
+    if (used_total[0] <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_mhl_pool(b, (size_t)used + (used >> 4) + 1024));
+    EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024));
   }
-  uint32_t *d_total = b->misc.as<uint32_t>() + 2;
-  EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
-  uint32_t total = 0;
-  EPI_TRY(read_scalars(b, s, d_total, 4, &total));
   b->last_kind = 2;
-  b->last_nrow = total;
-  *nrow_out = total;
+  b->last_nrow = used_total[1];
+  *nrow_out = used_total[1];
   return EPI_OK;
 }
 

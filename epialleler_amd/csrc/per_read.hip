@@ -16,6 +16,8 @@
 
 namespace epi {
 
+constexpr int PR_UN = 4;       // 16-byte loads a lane keeps in flight
+
 struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // weight bytes for codes 0-3, 4-7, 8-11, 12-15
 struct Luts { ClassLut c[4]; };
 
@@ -74,20 +76,32 @@ __global__ __launch_bounds__(256) void k_per_read(const uint8_t *__restrict__ xm
 #pragma unroll
   for (int k = 0; k < NCLS; k++) acc[k] = 0;
 
-  for (int64_t c = c0 + sub; c < c1; c += G) {
-    const int64_t g0 = c << 4;
-    const uint4 w = *reinterpret_cast<const uint4 *>(xm + g0);
-    uint32_t m0 = ~0u, m1 = ~0u, m2 = ~0u, m3 = ~0u;
-    if (g0 < rs || g0 + 16 > re) {                    // first / last chunk of the read: mask foreign bytes
-      m0 = byte_range_mask(rs - g0, re - g0);
-      m1 = byte_range_mask(rs - g0 - 4, re - g0 - 4);
-      m2 = byte_range_mask(rs - g0 - 8, re - g0 - 8);
-      m3 = byte_range_mask(rs - g0 - 12, re - g0 - 12);
+  // PR_UN independent 16-byte loads per lane are issued before any of them is consumed
+  for (int64_t cb = c0 + sub; cb < c1; cb += (int64_t)G * PR_UN) {
+    uint4 w[PR_UN];
+#pragma unroll
+    for (int u = 0; u < PR_UN; u++) {
+      const int64_t c = cb + (int64_t)u * G;
+      w[u] = c < c1 ? *reinterpret_cast<const uint4 *>(xm + (c << 4)) : make_uint4(0, 0, 0, 0);
     }
-    acc_dword<NCLS>(w.x, m0, L, acc);
-    acc_dword<NCLS>(w.y, m1, L, acc);
-    acc_dword<NCLS>(w.z, m2, L, acc);
-    acc_dword<NCLS>(w.w, m3, L, acc);
+#pragma unroll
+    for (int u = 0; u < PR_UN; u++) {
+      const int64_t c = cb + (int64_t)u * G;
+      if (c < c1) {
+        const int64_t g0 = c << 4;
+        uint32_t m0 = ~0u, m1 = ~0u, m2 = ~0u, m3 = ~0u;
+        if (g0 < rs || g0 + 16 > re) {                // first / last chunk of the read: mask foreign bytes
+          m0 = byte_range_mask(rs - g0, re - g0);
+          m1 = byte_range_mask(rs - g0 - 4, re - g0 - 4);
+          m2 = byte_range_mask(rs - g0 - 8, re - g0 - 8);
+          m3 = byte_range_mask(rs - g0 - 12, re - g0 - 12);
+        }
+        acc_dword<NCLS>(w[u].x, m0, L, acc);
+        acc_dword<NCLS>(w[u].y, m1, L, acc);
+        acc_dword<NCLS>(w[u].z, m2, L, acc);
+        acc_dword<NCLS>(w[u].w, m3, L, acc);
+      }
+    }
   }
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) {
@@ -126,13 +140,11 @@ __global__ __launch_bounds__(256) void k_per_read(const uint8_t *__restrict__ xm
 static int pick_group(const epi_batch *b) {
   const char *env = getenv("EPIHIP_GROUP");
   if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
+  // lanes per read: few enough that every lane streams >= 2*PR_UN chunks of its read
   const int64_t mean = b->n > 0 ? b->nbytes / b->n : 0;
-  const int64_t chunks = mean / 16 + 1;
-  int p = 1;
-  while (p < chunks && p < 128) p <<= 1;
-  int g = p / 2;
-  if (g < 1) g = 1;
-  if (g > 64) g = 64;
+  const int64_t chunks = mean / 16 + 2;
+  int g = 4;
+  while (g < 64 && (int64_t)g * PR_UN * 2 < chunks) g <<= 1;   // two passes of PR_UN loads per lane measured fastest
   return g;
 }
 

@@ -10,10 +10,12 @@
 // (src/rcpp_cx_report.cpp:113) and the key sort of a sort+segmented-reduce
 // scheme: the input order already is the sort.
 #include "common.hpp"
+#include <string.h>
 
 namespace epi {
 
-__device__ __forceinline__ int64_t tile_of(int64_t pos, int32_t T) { return (pos + kPosBias) / T; }
+// T is a power of two: tile index by shift (sh = log2 T)
+__device__ __forceinline__ int64_t tile_of(int64_t pos, int32_t sh) { return (pos + kPosBias) >> sh; }
 
 __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                     const int32_t *__restrict__ strand, const int64_t *__restrict__ off,
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
     bad_len |= __shfl_xor(bad_len, d, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (len) atomicMax(&st->max_len, len);
+    // uniform-length input: after the first few waves the cached maximum already covers `len`
+    if (len > __atomic_load_n(&st->max_len, __ATOMIC_RELAXED)) atomicMax(&st->max_len, len);
     if (unsorted) atomicOr(&st->unsorted, 1);
     if (bad_strand) atomicOr(&st->bad_strand, 1);
     if (bad_len) atomicOr(&st->bad_len, 1);
@@ -48,55 +51,66 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
 
 // tiles row x must create: (lo .. b], see header comment
 __device__ __forceinline__ void row_tile_span(const int32_t *start, const int32_t *rname, int64_t x, int32_t lmax,
-                                              int32_t T, int64_t *lo, int64_t *b) {
+                                              int32_t sh, int64_t *lo, int64_t *b) {
   const int64_t s = start[x];
-  const int64_t a = tile_of(s, T);
-  *b = tile_of(s + lmax - 1, T);
+  const int64_t a = tile_of(s, sh);
+  *b = tile_of(s + lmax - 1, sh);
   *lo = a;
   if (x > 0 && rname[x - 1] == rname[x]) {
-    const int64_t bp = tile_of((int64_t)start[x - 1] + lmax - 1, T);
+    const int64_t bp = tile_of((int64_t)start[x - 1] + lmax - 1, sh);
     if (bp + 1 > *lo) *lo = bp + 1;
   }
 }
 
 __global__ __launch_bounds__(256) void k_tile_counts(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
-                                                      int64_t n, int32_t lmax, int32_t T, uint32_t *__restrict__ cnt) {
+                                                      int64_t n, const RowStats *__restrict__ st, int32_t sh,
+                                                      uint32_t *__restrict__ cnt) {
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (x >= n) return;
+  const int32_t lmax = st->max_len > 0 ? st->max_len : 1;   // written by k_row_stats earlier on this stream
   int64_t lo, b;
-  row_tile_span(start, rname, x, lmax, T, &lo, &b);
+  row_tile_span(start, rname, x, lmax, sh, &lo, &b);
   cnt[x] = b >= lo ? (uint32_t)(b - lo + 1) : 0u;
 }
 
-// first row y in [0,n) with (rname[y], start[y]) >= (r, s)
-__device__ __forceinline__ int64_t lower_bound_rows(const int32_t *rname, const int32_t *start, int64_t n, int32_t r, int64_t s) {
-  int64_t lo = 0, hi = n;
+// First row y >= x of rname r with start[y] >= s (rows are sorted): gallop forward from x, then bisect.
+// The rows of one tile are a few hundred at most, so this is ~2*log2(rows per tile) dependent loads.
+__device__ __forceinline__ int64_t gallop_rows(const int32_t *rname, const int32_t *start, int64_t n, int64_t x,
+                                               int32_t r, int64_t s) {
+  auto less = [&](int64_t y) { const int32_t rm = rname[y]; return rm < r || (rm == r && (int64_t)start[y] < s); };
+  int64_t lo = x, step = 64;
+  int64_t hi = x + step;
+  while (hi < n && less(hi)) { lo = hi + 1; step <<= 1; hi = lo + step; }
+  if (hi > n) hi = n;
   while (lo < hi) {
     const int64_t mid = lo + ((hi - lo) >> 1);
-    const int32_t rm = rname[mid];
-    const bool less = rm < r || (rm == r && (int64_t)start[mid] < s);
-    if (less) lo = mid + 1; else hi = mid;
+    if (less(mid)) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
 
 __global__ __launch_bounds__(256) void k_tile_fill(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
-                                                    int64_t n, int32_t lmax, int32_t T, const uint32_t *__restrict__ row_off,
-                                                    Tile *__restrict__ tiles, const int64_t *__restrict__ shared_keys,
-                                                    int32_t nshared) {
+                                                    int64_t n, const RowStats *__restrict__ st, int32_t sh,
+                                                    const uint32_t *__restrict__ row_off, Tile *__restrict__ tiles,
+                                                    const int64_t *__restrict__ shared_keys, int32_t nshared) {
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (x >= n) return;
+  const int32_t lmax = st->max_len > 0 ? st->max_len : 1;
+  const int64_t T = 1LL << sh;
   int64_t lo, b;
-  row_tile_span(start, rname, x, lmax, T, &lo, &b);
+  row_tile_span(start, rname, x, lmax, sh, &lo, &b);
   if (b < lo) return;
   const int32_t r = rname[x];
   uint32_t slot_base = row_off[x];
+  int64_t from = x;
   for (int64_t t = lo; t <= b; t++) {
     Tile td;
     td.pos0 = t * T - kPosBias;
     td.rname = r;
-    td.row_lo = (int32_t)lower_bound_rows(rname, start, n, r, td.pos0 - lmax + 1);
-    td.row_hi = (int32_t)lower_bound_rows(rname, start, n, r, td.pos0 + T);
+    // The row that creates a tile is the first one that can reach it (start >= pos0 - lmax + 1): it IS row_lo.
+    td.row_lo = (int32_t)x;
+    from = gallop_rows(rname, start, n, from, r, td.pos0 + T);   // first row starting beyond the tile
+    td.row_hi = (int32_t)from;
     td.slot = -1;
     if (nshared > 0) {
       const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
@@ -108,38 +122,44 @@ __global__ __launch_bounds__(256) void k_tile_fill(const int32_t *__restrict__ s
   }
 }
 
-int build_row_stats(epi_batch *b, hipStream_t s, RowStats *h) {
-  EPI_TRY(b->stats.ensure(sizeof(RowStats)));
-  EPI_HIP(hipMemsetAsync(b->stats.p, 0, sizeof(RowStats), s));
-  if (b->n > 0) {
-    const unsigned nb = (unsigned)((b->n + 255) / 256);
-    hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n,
-                       b->stats.as<RowStats>());
-    EPI_HIP(hipGetLastError());
-  }
-  EPI_TRY(read_scalars(b, s, b->stats.p, sizeof(RowStats), h));
-  if (h->bad_len) return fail(EPI_ERR_ARG, "offsets are not non-decreasing, or start+length exceeds int32");
-  if (h->bad_strand) return fail(EPI_ERR_ARG, "strand values must be 1 ('+') or 2 ('-')");
-  return EPI_OK;
+static int log2_tile(int32_t T) {
+  int sh = 0;
+  while ((1 << sh) < T) sh++;
+  return sh;
 }
 
-int build_tiles(epi_batch *b, hipStream_t s, int32_t max_len, int32_t T, int32_t *ntiles_out) {
+// Row statistics + tile table with ONE host synchronisation: k_row_stats -> k_tile_counts (reads the maximum
+// length on the device) -> scan -> read back {stats, tile count} -> k_tile_fill.
+int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *ntiles_out) {
   *ntiles_out = 0;
+  memset(h, 0, sizeof(*h));
+  if ((T & (T - 1)) != 0) return fail(EPI_ERR_ARG, "tile size must be a power of two");
+  const int sh = log2_tile(T);
+  EPI_TRY(b->misc.ensure(256));
+  // misc layout (u32): [0] tile count, [1] pool cursor, [2] output rows, [4..7] RowStats
+  uint32_t *d_misc = b->misc.as<uint32_t>();
+  RowStats *d_st = reinterpret_cast<RowStats *>(d_misc + 4);
+  EPI_HIP(hipMemsetAsync(d_misc, 0, 32, s));
   if (b->n == 0) return EPI_OK;
-  const int32_t lmax = max_len > 0 ? max_len : 1;
   const unsigned nb = (unsigned)((b->n + 255) / 256);
   EPI_TRY(b->row_cnt.ensure((size_t)b->n * 4));
   EPI_TRY(b->row_off.ensure((size_t)b->n * 4));
-  EPI_TRY(b->misc.ensure(256));
-  uint32_t *d_total = b->misc.as<uint32_t>();   // misc[0] = tile count
-  hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, lmax, T, b->row_cnt.as<uint32_t>());
-  EPI_TRY(scan_exclusive_u32(b->row_cnt.as<uint32_t>(), b->row_off.as<uint32_t>(), b->n, d_total, b->scan_tmp, s));
-  uint32_t nt = 0;
-  EPI_TRY(read_scalars(b, s, d_total, 4, &nt));
+  hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, d_st);
+  hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, d_st, sh, b->row_cnt.as<uint32_t>());
+  EPI_TRY(scan_exclusive_u32(b->row_cnt.as<uint32_t>(), b->row_off.as<uint32_t>(), b->n, d_misc, b->scan_tmp, s));
+  uint32_t host[8];
+  EPI_TRY(read_scalars(b, s, d_misc, 32, host));
+  memcpy(h, host + 4, sizeof(RowStats));
+  if (h->bad_len) return fail(EPI_ERR_ARG, "offsets are not non-decreasing, or start+length exceeds int32");
+  if (h->bad_strand) return fail(EPI_ERR_ARG, "strand values must be 1 ('+') or 2 ('-')");
+  if (h->unsorted)
+    return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start); the reference requires a pre-sorted dataset "
+                                  "(src/rcpp_cx_report.cpp:19)");
+  const uint32_t nt = host[0];
   if (nt > 0x7FFFFFF0u) return fail(EPI_ERR_ARG, "too many tiles (%u)", nt);
   EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
   const int32_t nshared = (int32_t)b->shared_keys.size();
-  hipLaunchKernelGGL(k_tile_fill, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, lmax, T, b->row_off.as<uint32_t>(),
+  hipLaunchKernelGGL(k_tile_fill, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, d_st, sh, b->row_off.as<uint32_t>(),
                      b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared);
   EPI_HIP(hipGetLastError());
   *ntiles_out = (int32_t)nt;
