@@ -50,11 +50,14 @@ struct CxArgs {
   uint32_t *cursor;                       // rows handed out so far (may exceed pool_cap: overflow)
   uint32_t *tile_nrow, *tile_base;
   int32_t *slab;                          // shared-tile counters [slot][16][T]
+  int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit
 };
 
 struct RowSlice {                         // the part of one row that falls inside the tile, seen from one lane
   const uint32_t *src;                    // this lane's first dword of the (dword-aligned) slice in xm
-  uint32_t *dst;                          // LDS cell of byte 0 of that dword in counter plane 0 of the row's strand
+  uint32_t *dst[4];                       // LDS cells (counter plane 0 of the row's strand) of the lane's first dword,
+                                          // in the order the lane walks its four bytes (see rot8)
+  int rot8;                               // 8 * byte rotation: sub-step j handles byte (j + rot) & 3
   int nd;                                 // dwords in the slice (0 = nothing to do)
   uint32_t lc4;                           // 0x08080808 when the read failed thresholding (lower-case, :118)
   uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
@@ -63,7 +66,8 @@ struct RowSlice {                         // the part of one row that falls insi
 template <int T, int G>
 __device__ __forceinline__ RowSlice cx_row_slice(const CxArgs &a, const Tile &td, int r, int sub, uint32_t *cnt) {
   RowSlice m;
-  m.src = nullptr; m.dst = cnt; m.nd = 0; m.lc4 = 0; m.mask_first = ~0u; m.mask_last = ~0u;
+  m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.lc4 = 0;
+  m.mask_first = ~0u; m.mask_last = ~0u;
   if (r < td.row_hi) {
     const int32_t st = a.start[r];
     const int64_t o = a.off[r];
@@ -80,7 +84,16 @@ __device__ __forceinline__ RowSlice cx_row_slice(const CxArgs &a, const Tile &td
       const int32_t e_hi = e_lo + (hi - lo);
       m.nd = (e_hi + 3) >> 2;
       m.src = reinterpret_cast<const uint32_t *>(a.xm + (b0 - e_lo)) + sub;
-      m.dst = cnt + (sd - 1) * 8 * T + (lo - rel - e_lo) + 4 * sub;
+      // Bank-conflict-free LDS atomics: at sub-step j a lane adds at position d + 4*sub' + ((j+rot)&3), i.e. in
+      // bank residue (d + j + rot) mod 4.  The 8 lanes of one "eighth" of a 32-lane half are 4 cells apart
+      // (8 banks of one residue); rot = eighth - d gives the four eighths the residues j, j+1, j+2, j+3 whatever
+      // rows (and row alignments d) they work on, so the 32 lanes always hit 32 different banks.
+      const int d = lo - rel - e_lo;
+      const int rot = ((int)((threadIdx.x & 31) >> 3) - d) & 3;
+      uint32_t *dst0 = cnt + (sd - 1) * 8 * T + d + 4 * sub;
+      m.rot8 = rot * 8;
+#pragma unroll
+      for (int j = 0; j < 4; j++) m.dst[j] = dst0 + ((j + rot) & 3);
       m.lc4 = ps == 0 ? 0x08080808u : 0u;
       m.mask_first = sub == 0 ? 0xFFFFFFFFu << (8 * e_lo) : ~0u;
       m.mask_last = 0xFFFFFFFFu >> (8 * (4 * m.nd - e_hi));
@@ -92,9 +105,10 @@ __device__ __forceinline__ RowSlice cx_row_slice(const CxArgs &a, const Tile &td
 // One dword (four bases) of a row into the LDS counters.  Every lane issues all four atomics: bytes
 // outside the slice and skipped codes are turned into "+0 on plane 0" by the masks, never branched
 // around.  A masked byte can sit up to 3 cells outside [0,T): the counters carry kCxGuard cells of
-// padding for that.  `rot` staggers the byte order so lanes l and l+8 (32 dwords apart) hit different banks.
+// padding for that.  The byte order is rotated per lane (RowSlice::rot8) so that the 32 lanes of a half
+// wavefront always hit 32 different LDS banks.
 template <int T, int OFF, bool FIRST>
-__device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m, int rot8) {
+__device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m) {
   const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
   const uint32_t lo3 = c4 & 0x07070707u;
   const uint32_t b3 = (c4 >> 3) & 0x01010101u;
@@ -104,26 +118,26 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &
   uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
   if (FIRST) vm &= m.mask_first;
   s4 &= vm;
-  s4 = __builtin_amdgcn_alignbit(s4, s4, rot8);          // rotate right by rot bytes: byte q <- byte (q+rot)&3
-  uint32_t *base = m.dst + OFF;                          // OFF = 4 * (this dword's index - the lane's first index)
+  s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint32_t plane = (s4 >> (8 * q)) & 7u;
-    const uint32_t inc = (s4 >> (8 * q + 4)) & 3u;
-    atomicAdd(base + plane * T + ((q + (rot8 >> 3)) & 3), inc);
+  for (int j = 0; j < 4; j++) {                          // OFF = 4 * (this dword's index - the lane's first index)
+    const uint32_t plane = (s4 >> (8 * j)) & 7u;
+    const uint32_t inc = (s4 >> (8 * j + 4)) & 3u;
+    atomicAdd(m.dst[j] + OFF + plane * T, inc);
   }
 }
 
 // Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
 // (64/G rows per wavefront step); a lane keeps CX_UN dword loads of its row in flight and the next
-// step's row metadata is fetched before the current step's atomics are issued.
-template <int T, int G>
+// step's row metadata is fetched before the current step's atomics are issued.  (A deeper software
+// pipeline -- bytes one step ahead, columns three -- measured slower: the kernel is issue-bound, not
+// latency-bound, once two workgroups share a CU.)
+template <int T, int G, int WG>
 __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
   constexpr int R = 64 / G;
-  constexpr int NW = CX_WG / 64;
+  constexpr int NW = WG / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
-  const int rot8 = ((sub >> 3) & 3) * 8;
   int r = td.row_lo + wave * R + grp;
   RowSlice cur = cx_row_slice<T, G>(a, td, r, sub, cnt);
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
@@ -135,15 +149,16 @@ __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, u
     }
     r += NW * R;
     const RowSlice nxt = cx_row_slice<T, G>(a, td, r, sub, cnt);
-    if (sub < cur.nd) cx_add_dword<T, 0, true>(w[0], sub, cur, rot8);
-    if (sub + G < cur.nd) cx_add_dword<T, 4 * G, false>(w[1], sub + G, cur, rot8);
-    if (sub + 2 * G < cur.nd) cx_add_dword<T, 8 * G, false>(w[2], sub + 2 * G, cur, rot8);
-    if (sub + 3 * G < cur.nd) cx_add_dword<T, 12 * G, false>(w[3], sub + 3 * G, cur, rot8);
-    if (sub + 4 * G < cur.nd) cx_add_dword<T, 16 * G, false>(w[4], sub + 4 * G, cur, rot8);
+    if (sub < cur.nd) cx_add_dword<T, 0, true>(w[0], sub, cur);
+    if (sub + G < cur.nd) cx_add_dword<T, 4 * G, false>(w[1], sub + G, cur);
+    if (sub + 2 * G < cur.nd) cx_add_dword<T, 8 * G, false>(w[2], sub + 2 * G, cur);
+    if (sub + 3 * G < cur.nd) cx_add_dword<T, 12 * G, false>(w[3], sub + 3 * G, cur);
+    if (sub + 4 * G < cur.nd) cx_add_dword<T, 16 * G, false>(w[4], sub + 4 * G, cur);
     for (int k = sub + CX_UN * G; k < cur.nd; k += G) {   // slices longer than CX_UN*G dwords (long reads, small G)
       RowSlice t = cur;
-      t.dst = cur.dst + 4 * (k - sub);
-      cx_add_dword<T, 0, false>(cur.src[k - sub], k, t, rot8);
+#pragma unroll
+      for (int j = 0; j < 4; j++) t.dst[j] = cur.dst[j] + 4 * (k - sub);
+      cx_add_dword<T, 0, false>(cur.src[k - sub], k, t);
     }
     cur = nxt;
   }
@@ -165,12 +180,12 @@ __device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, u
 }
 
 // Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
-template <int T>
+template <int T, int WG>
 __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
-  constexpr int PPT = T / CX_WG;                          // consecutive positions per thread
+  constexpr int PPT = T / WG;                          // consecutive positions per thread
   static_assert(PPT == 1 || PPT == 2 || PPT == 4, "emit phase layout");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = CX_WG / 64;
+  constexpr int NW = WG / 64;
   const int p0 = threadIdx.x * PPT;
   uint32_t key[2 * PPT], me[2 * PPT], un[2 * PPT];       // statically indexed (fully unrolled): stay in VGPRs
   bool ok[2 * PPT];
@@ -227,35 +242,47 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
   }
 }
 
-template <int T, int G>
-__global__ __launch_bounds__(CX_WG) void k_cx_tiles(CxArgs a) {
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
+// Giving XCD x the contiguous tile range [x*chunk, (x+1)*chunk) makes the tiles that run together on
+// an XCD genomic neighbours, so the rows two adjacent tiles both read are served from that L2.
+// Bijective on [0, 8*chunk) >= ntiles; purely a speed choice (results do not depend on placement).
+__device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
+  const int chunk = (ntiles + 7) >> 3;
+  return (b & 7) * chunk + (b >> 3);
+}
+
+// two workgroups per CU: 64 KiB of LDS each, and at WG = 1024 the VGPR budget of 8 waves per SIMD (64)
+template <int T, int G, int WG>
+__global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_tiles(CxArgs a, int ntiles) {
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[kCxPlanes * T + 2 * kCxGuard];
-  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  __shared__ uint32_t s_scan[WG / 64 + 2];
   uint32_t *cnt = cnt_raw + kCxGuard;
-  const int tile = blockIdx.x;
+  const int tile = cx_tile_of_block(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
   uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const Tile td = a.tiles[tile];
-  cx_accumulate<T, G>(a, td, cnt);
+  if (!(a.ablate & 1)) cx_accumulate<T, G, WG>(a, td, cnt);
   __syncthreads();
   if (td.slot >= 0) {
     // shared with another rank (or split over several work items): hand the raw counters over
     int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * T);
-    for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) {
+    for (int i = threadIdx.x; i < kCxPlanes * T; i += WG) {
       const uint32_t v = cnt[i];
       if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
     }
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
-  cx_emit<T>(a, tile, cnt, s_scan);
+  if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
+  cx_emit<T, WG>(a, tile, cnt, s_scan);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
 template <int T>
 __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned, int ntiles) {
-  __shared__ uint32_t cnt[kCxPlanes * T];
+  __shared__ __attribute__((aligned(16))) uint32_t cnt[kCxPlanes * T];
   __shared__ uint32_t s_scan[CX_WG / 64 + 2];
   const int tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -264,7 +291,7 @@ __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t 
   const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * T);
   for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
   __syncthreads();
-  cx_emit<T>(a, tile, cnt, s_scan);
+  cx_emit<T, CX_WG>(a, tile, cnt, s_scan);
 }
 
 // Output row i -> its tile (binary search in the exclusive scan of tile row counts) -> decode.
@@ -300,7 +327,7 @@ static int pick_cx_group(int32_t max_len, int T) {
   const int slice = (max_len < T ? max_len : T) + 3;
   const int nd = (slice + 3) / 4;
   int g = 8;
-  while (g < 64 && g * CX_UN < nd) g <<= 1;
+  while (g < 64 && g * CX_UN * 2 < nd) g <<= 1;   // up to two passes of CX_UN dwords per lane measured fastest
   return g;
 }
 
@@ -313,20 +340,31 @@ int cx_tile_positions() {
   return t;
 }
 
-template <int T>
+template <int T, int WG>
 static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
+  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_cx_tiles<T, 64>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
   }
 }
 
+static int cx_workgroup_size() {
+  static int wg = 0;
+  if (!wg) {
+    wg = 1024;                                  // 2 x 16 wavefronts per CU measured fastest (profiles/)
+    if (const char *env = getenv("EPIHIP_CX_WG")) { const int v = atoi(env); if (v == 512 || v == 1024) wg = v; }
+  }
+  return wg;
+}
+
 static void launch_cx_tiles(int T, int g, int nt, hipStream_t s, const CxArgs &a) {
-  if (T == 512) launch_cx_tiles_g<512>(g, nt, s, a);
-  else if (T == 2048) launch_cx_tiles_g<2048>(g, nt, s, a);
-  else launch_cx_tiles_g<1024>(g, nt, s, a);
+  const bool big = cx_workgroup_size() == 1024;
+  if (T == 512) launch_cx_tiles_g<512, 512>(g, nt, s, a);
+  else if (T == 2048) { if (big) launch_cx_tiles_g<2048, 1024>(g, nt, s, a); else launch_cx_tiles_g<2048, 512>(g, nt, s, a); }
+  else { if (big) launch_cx_tiles_g<1024, 1024>(g, nt, s, a); else launch_cx_tiles_g<1024, 512>(g, nt, s, a); }
 }
 
 static void launch_cx_emit_slab(int T, int nt, hipStream_t s, const CxArgs &a, const int32_t *owned) {
@@ -384,6 +422,8 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
   a.slab = b->d_slab;
+  a.ablate = 0;
+  if (const char *env = getenv("EPIHIP_CX_ABLATE")) a.ablate = atoi(env);
   const int32_t nshared = (int32_t)b->shared_keys.size();
 
   // Shared tiles are emitted later (epi_batch_cx_finish_shared) into the same pool: keep room for them.
