@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rows timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--gather", action="store_true", help="N>1: also send every rank's rows to rank 0 inside the timed step")
+    ap.add_argument("--check", action="store_true", help="rank 0 checks the gathered table against a single-GPU run of the whole stream")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,11 +60,16 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import epialleler_amd as ea
     from epialleler_amd import _lib, distributed as D, synth
@@ -82,7 +91,7 @@ def main():
             return ea.generateCytosineReport(bam, threshold_reads=wl["threshold"], report_context=wl["report_context"],
                                              as_device=True)
         return D.sharded_cytosine_report(eng, threshold_reads=wl["threshold"], report_context=wl["report_context"],
-                                         gather=True, levels=bam.levels)
+                                         gather=args.gather or args.check, levels=bam.levels)
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,9 +128,23 @@ def main():
         if c2.value:
             kernels[nm.decode()] = round(m2.value / c2.value, 4)
 
+    if args.check and world > 1 and rank == 0 and wl["kind"] == "cx":
+        whole = synth.generate_device(n_total=n_total, read_len=L, device=local)
+        ref = ea.generateCytosineReport(whole, threshold_reads=wl["threshold"], report_context=wl["report_context"], as_device=True)
+        ok = all(bool(torch.equal(ref[k], rep[k])) for k in ref)
+        print("CHECK sharded == single-GPU table: %s (%d rows)" % (ok, ref.nrow), flush=True)
+        whole.close()
+        if not ok:
+            raise SystemExit("sharded result differs from the single-GPU result")
+    gathered = world > 1 and (args.gather or args.check)
+    nrow_local = rep.nrow if rep is not None else 0
+    nrow_out = nrow_local
+    if world > 1 and not gathered:
+        tot = torch.tensor([nrow_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        nrow_out = int(tot.item())
     if rank == 0:
-        nrow_out = rep.nrow if rep is not None else 0
-        rows_this_rank = nrow_out if world == 1 else nrow_out // world   # emitted per rank (approx. at N>1)
+        rows_this_rank = nrow_local if not gathered else nrow_out // world   # rows rank 0's kernel emitted
         row_bytes = 36 if wl["kind"] == "mhl" else 24
         # L (xm) + 8 (off) + 12 (rname,strand,start) + 4 (pass) per read, + 24/36 B per output row
         alg_bytes = rows * (L + 8 + 12 + 4) + row_bytes * rows_this_rank
@@ -145,7 +168,8 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
-                       "inputs": "resident in HBM", "sharding": "row ranges, shared tiles all-reduced (RCCL)" if world > 1 else "none"},
+                       "inputs": "resident in HBM", "sharding": ("row ranges; shared tiles all-reduced (RCCL); output rows %s"
+                                    % ("gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname.decode(), "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kms, 4),

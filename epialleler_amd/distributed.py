@@ -15,8 +15,11 @@ ranks.  One exchange step:
   4. all_reduce(sum) of the slab                                   -- RCCL, KBs..MBs
   5. the owner applies the majority rule to its shared tiles; rows of a rank
      stay in (rname,pos,strand) order and rank order is genomic order
-  6. rows are sent to rank 0, which concatenates them in rank order -- the one
-     table generateCytosineReport() returns (R/generateCytosineReport.R:200-207).
+  6. optionally (gather=True) rows are sent to rank 0, which concatenates them in
+     rank order -- the one table generateCytosineReport() returns
+     (R/generateCytosineReport.R:200-207).  With gather=False every rank keeps its
+     rows in HBM; the logical table is their concatenation in rank order (a report
+     file is then written as one part per rank).
 
 The engine behind a shard is abstract (`ShardEngine`) so that the exchange logic
 runs unchanged on CPU tensors under gloo in tests (tests/fake_engine.py supplies
@@ -72,14 +75,18 @@ class HipShardEngine:
         self.lib = _lib.load()
         self.device = torch.device("cuda", self.bam.device)
         self._slab = None
+        self._range = None
 
     def tile_positions(self):
         return self.lib.epi_tile_positions()
 
     def key_range(self):
-        a, b = C.c_int64(0), C.c_int64(-1)
-        _lib.check(self.lib.epi_batch_tile_key_range(self.h, _stream(self.bam.device), C.byref(a), C.byref(b)))
-        return a.value, b.value
+        # a property of the resident (immutable) shard and the tile grid: computed once
+        if self._range is None:
+            a, b = C.c_int64(0), C.c_int64(-1)
+            _lib.check(self.lib.epi_batch_tile_key_range(self.h, _stream(self.bam.device), C.byref(a), C.byref(b)))
+            self._range = (a.value, b.value)
+        return self._range
 
     def threshold(self, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n, min_frac, max_oo):
         from .api import rcpp_threshold_reads
