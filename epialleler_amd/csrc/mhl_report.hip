@@ -19,14 +19,13 @@
 // sum(h), sum(S(m_i)), sum(S(h)) and 512-position tiles (56 KiB of LDS).
 // S(n) = n(n+1)(n+2)/6 is computed arithmetically (no 64K-entry table).
 #include "common.hpp"
+#include "tile_common.hpp"
 #include <stdlib.h>
 #include <string.h>
 
 namespace epi {
 
 constexpr int MHL_WG = 512;
-constexpr int MHL_PPT = kMhlTile / MHL_WG;      // 1 position per thread in the emit phase
-static_assert(MHL_PPT == 1, "emit phase assumes one position per thread");
 
 __host__ __device__ __forceinline__ uint64_t nrS(uint64_t n) { return n < 2 ? n : (n * (n + 1) * (n + 2)) / 6; }   // :39-43
 // mhl_lookup[n] (:110-116) without the table; indices clamp at 65535 (the reference's table ends there)
@@ -57,8 +56,95 @@ __global__ __launch_bounds__(256) void k_mhl_rows(const uint8_t *__restrict__ xm
   const int64_t c1 = re > rs ? (re + 15) >> 4 : c0;
   const int64_t nblk = (c1 - c0 + G - 1) / G;
 
+  if (nblk == 1) {
+    // ---- whole read inside one block of 16*G bytes: everything stays in registers ----
+    const int64_t c = c0 + sub;
+    const int64_t g0 = c << 4;
+    const bool live = c < c1;
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (live) w = *reinterpret_cast<const uint4 *>(xm + g0);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    uint32_t Ub = 0, Lb = 0, Mb = 0, Nb = 0, Vb = 0;       // per-byte bit masks: member, cut, ooctx meth/unmeth, in-row
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int64_t g = g0 + i;
+      const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
+      const uint32_t inrow = (live && g >= rs && g < re) ? 1u : 0u;
+      const uint32_t in = inrow & (ctx_mask >> code) & 1u;
+      Vb |= inrow << i;
+      Ub |= (in & (code < 8u ? 1u : 0u)) << i;
+      Lb |= (in & (code >= 8u ? 1u : 0u)) << i;
+      Mb |= (inrow & ~in & ((0x00E4u >> code) & 1u)) << i;   // codes 2,5,6,7   (:176)
+      Nb |= (inrow & ~in & ((0xE400u >> code) & 1u)) << i;   // codes 10,13,14,15 (:177)
+    }
+    uint32_t h = __popc(Ub | Lb), oo_m = __popc(Mb), oo_u = __popc(Nb);
+    // forward
+    uint32_t a0[16], b0[16];
+    Seg mf = {0u, 0u}, mb = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if ((Lb >> i) & 1u) { mf.has = 1u; mf.cnt = 0u; } else mf.cnt += (Ub >> i) & 1u;
+      a0[i] = mf.cnt;
+    }
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+      if ((Lb >> i) & 1u) { mb.has = 1u; mb.cnt = 0u; } else mb.cnt += (Ub >> i) & 1u;
+      b0[i] = mb.cnt;
+    }
+    Seg incf = mf, incb = mb;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+      Seg l, r2;
+      l.has = __shfl_up(incf.has, d, G); l.cnt = __shfl_up(incf.cnt, d, G);
+      if (sub >= d) incf = seg_combine(l, incf);
+      r2.has = __shfl_down(incb.has, d, G); r2.cnt = __shfl_down(incb.cnt, d, G);
+      if (sub + d < G) incb = seg_combine(r2, incb);
+    }
+    Seg ef, eb;
+    ef.has = __shfl_up(incf.has, 1, G); ef.cnt = __shfl_up(incf.cnt, 1, G);
+    if (sub == 0) { ef.has = 0u; ef.cnt = 0u; }
+    eb.has = __shfl_down(incb.has, 1, G); eb.cnt = __shfl_down(incb.cnt, 1, G);
+    if (sub == G - 1) { eb.has = 0u; eb.cnt = 0u; }
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1) {
+      h += __shfl_xor(h, d, 64);
+      oo_m += __shfl_xor(oo_m, d, 64);
+      oo_u += __shfl_xor(oo_u, d, 64);
+    }
+    bool keep = true;
+    {
+      const double frac = (double)oo_m / (double)((uint64_t)oo_m + oo_u);      // :178 (0/0 = NaN -> kept)
+      if ((int)h < hmin || frac > max_oo) keep = false;                        // :179
+    }
+    if (valid && sub == 0) rowinfo[row] = keep ? (int32_t)h : -1;
+    if (!keep || !live) return;
+    // bits at or after the first cut / at or before the last cut of this chunk
+    const uint32_t cut_f = Lb ? ~((Lb & (0u - Lb)) - 1u) : 0u;
+    const uint32_t cut_b = Lb ? ((2u << (31 - __clz(Lb))) - 1u) : 0u;
+    uint32_t mv[8];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      uint32_t av = a0[i], bv = b0[i];
+      if (!((cut_f >> i) & 1u)) av += ef.cnt;
+      if (!((cut_b >> i) & 1u)) bv += eb.cnt;
+      uint32_t m = 0;
+      if (!((Lb >> i) & 1u) && av > 0u && bv > 0u) { m = av + bv - ((Ub >> i) & 1u); if (m > 65535u) m = 65535u; }
+      if (i & 1) mv[i >> 1] |= m << 16; else mv[i >> 1] = m;
+    }
+    uint16_t *dst = m_out + g0;
+    if (Vb == 0xFFFFu) {                                  // whole chunk inside the read: two 16-byte stores
+      reinterpret_cast<uint4 *>(dst)[0] = make_uint4(mv[0], mv[1], mv[2], mv[3]);
+      reinterpret_cast<uint4 *>(dst)[1] = make_uint4(mv[4], mv[5], mv[6], mv[7]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if ((Vb >> i) & 1u) dst[i] = (uint16_t)((mv[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+    }
+    return;
+  }
+
   uint32_t h = 0, oo_m = 0, oo_u = 0;
-  // ---- forward: A(i) -> m_out (temporarily) ----
+  // ---- reads longer than one block: forward pass stores A(i) in m_out, backward pass turns it into m ----
   Seg carry = {0u, 0u};
   for (int64_t blk = 0; blk < nblk; blk++) {
     const int64_t c = c0 + blk * G + sub;
@@ -192,10 +278,9 @@ __global__ __launch_bounds__(256) void k_mhl_rows(const uint8_t *__restrict__ xm
 }
 
 struct MhlArgs {
-  const uint8_t *xm;
+  RowCols c;                              // pass is always null here (no lower-casing in lMHL)
   const uint16_t *m;
-  const int64_t *off;
-  const int32_t *start, *strand, *rowinfo;
+  const int32_t *rowinfo;
   const Tile *tiles;
   uint32_t ctx_mask, H;
   uint32_t *pool_key, *pool_cov;
@@ -204,92 +289,191 @@ struct MhlArgs {
   uint32_t *cursor, *tile_nrow, *tile_base;
 };
 
-constexpr uint64_t kMhlSlotMap = 0x7510831164111211ull;   // same slots as the CX kernel
+constexpr int MHL_T = kMhlTile;
 
-__global__ __launch_bounds__(MHL_WG) void k_mhl_tiles(MhlArgs a) {
-  constexpr int T = kMhlTile;
-  __shared__ unsigned long long sum64[2 * 3 * T];   // [strand][hsum, num, den][pos]
-  __shared__ uint32_t cnt[16 * T];                  // [strand][8][pos]
-  __shared__ uint32_t s_scan[MHL_WG / 64 + 2];
-  const int tile = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = MHL_WG / 64;
-  for (int i = threadIdx.x; i < 16 * T; i += MHL_WG) cnt[i] = 0;
-  for (int i = threadIdx.x; i < 6 * T; i += MHL_WG) sum64[i] = 0ull;
-  __syncthreads();
-  const Tile td = a.tiles[tile];
-  const int rot = (lane >> 3) & 3;
+// nibble -> flags of the rarely taken per-byte path: 1 = '+'/'-' (skipped, :187), 2/4/8 = stray nibbles
+// 3/4/8, whose counter slot IS the numerator / denominator / haplotype-size sum in the reference (:190)
+//   code:  0 1 2 3 4 5 6 7 | 8 9 10 11 | 12..15
+//   flag:  0 0 0 2 4 0 0 0 | 8 0  0  1 |  0
+constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x01000008u, kFlagHi1 = 0x00000000u;
 
-  for (int rbase = td.row_lo + wave * 64; rbase < td.row_hi; rbase += NW * 64) {
-    const int r = rbase + lane;
-    int i_lo = 0, i_hi = 0, pbase = 0, sflag = 0, hrow = -1;
-    int64_t o = 0;
-    if (r < td.row_hi) {
-      hrow = a.rowinfo[r];
-      if (hrow >= 0) {
-        const int64_t st = a.start[r];
-        o = a.off[r];
-        const int64_t len = a.off[r + 1] - o;
-        const int64_t rel = td.pos0 - st;
-        const int64_t lo = rel > 0 ? rel : 0;
-        const int64_t hi = len < rel + T ? len : rel + T;
-        if (hi > lo) { i_lo = (int)lo; i_hi = (int)hi; }
-        pbase = (int)(-rel);
-        sflag = a.strand[r] - 1;
-      }
-    }
-    const int nrows = td.row_hi - rbase < 64 ? td.row_hi - rbase : 64;
-    for (int j = 0; j < nrows; j++) {
-      const int jl = __builtin_amdgcn_readlane(i_lo, j), jh = __builtin_amdgcn_readlane(i_hi, j);
-      if (jl >= jh) continue;
-      const int lo32 = __builtin_amdgcn_readlane((int)(uint32_t)o, j);
-      const int hi32 = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)o >> 32), j);
-      const int64_t jo = (int64_t)(((uint64_t)(uint32_t)hi32 << 32) | (uint32_t)lo32);
-      const int jp = __builtin_amdgcn_readlane(pbase, j);
-      const int js = __builtin_amdgcn_readlane(sflag, j);
-      const uint32_t jh_size = (uint32_t)__builtin_amdgcn_readlane(hrow, j);
-      const uint64_t den_inc = mhl_lut(jh_size, a.H);                       // :194
-      uint32_t *cb = cnt + js * (8 * T);
-      unsigned long long *sb = sum64 + js * (3 * T);
-      const int64_t b0 = jo + jl, b1 = jo + jh;
-      for (int64_t ad = (b0 & ~3LL) + 4 * lane; ad < b1; ad += 256) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(a.xm + ad);
-        const uint2 mm = *reinterpret_cast<const uint2 *>(a.m + ad);         // four u16 stretch sizes
+struct MhlSlice {
+  RowSlice rs;
+  const uint2 *msrc;                      // this lane's first four stretch sizes (u16 each), parallel to rs.src
+  int pos0;                               // tile position of byte 0 of this lane's first dword (may be -1..-3)
+  int pf, pe;                             // tile positions [pf, pe) the slice covers
+  int sidx;                               // 0 '+', 1 '-'
+  uint32_t h;                             // haplotype size of the row
+};
+
+template <int G>
+__device__ __forceinline__ MhlSlice mhl_row_slice(const MhlArgs &a, const Tile &td, int r, int sub, uint32_t *cnt) {
+  MhlSlice m;
+  m.rs = cx_row_slice<MHL_T, G>(a.c, td, r, sub, cnt);
+  m.msrc = nullptr; m.pos0 = 0; m.pf = 0; m.pe = 0; m.sidx = 0; m.h = 0;
+  if (m.rs.nd > 0) {
+    const int32_t hrow = a.rowinfo[r];
+    if (hrow < 0) { m.rs.nd = 0; return m; }            // read skipped by pass 1 (:179)
+    m.h = (uint32_t)hrow;
+    const int32_t st = a.c.start[r];
+    const int64_t o = a.c.off[r];
+    const int32_t len = (int32_t)((uint32_t)a.c.off[r + 1] - (uint32_t)o);
+    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)st);
+    const int32_t lo = rel > 0 ? rel : 0;
+    const int32_t hi = len < rel + MHL_T ? len : rel + MHL_T;
+    const int64_t b0 = o + lo;
+    const int32_t e_lo = (int32_t)b0 & 3;
+    m.msrc = reinterpret_cast<const uint2 *>(a.m + (b0 - e_lo)) + sub;
+    m.pf = lo - rel;
+    m.pe = hi - rel;
+    m.pos0 = m.pf - e_lo + 4 * sub;
+    m.sidx = a.c.strand[r] - 1;
+  }
+  return m;
+}
+
+struct MhlLds {
+  uint32_t *cnt;                          // [2][8][T] code counters (as the CX kernel)
+  unsigned long long *num;                // [2][T]    sum of S(m_i)                       (:193)
+  unsigned long long *dh, *dd;            // [2][T+1]  difference arrays of sum(h) (:192) and sum(S(h)) (:194)
+};
+
+// One dword of a row: the CX counters, plus -- only where a byte needs it -- the numerator sum, the
+// corrections for skipped bytes and the stray-nibble increments.  sum(h) and sum(S(h)) are the same for
+// every counted byte of a row, so they are added as an interval (+v at the slice start, -v after its end,
+// prefix-summed at emit time) instead of one 64-bit atomic per byte.
+template <int OFF, bool FIRST>
+__device__ __forceinline__ void mhl_add_dword(uint32_t w, uint2 mm, int k, const MhlSlice &m, const MhlLds &L,
+                                              uint32_t H, unsigned long long sh) {
+  cx_add_dword<MHL_T, OFF, FIRST>(w, k, m.rs);
+  const uint32_t c4 = w & 0x0F0F0F0Fu;
+  const uint32_t lo3 = c4 & 0x07070707u;
+  const uint32_t b3 = (c4 >> 3) & 0x01010101u;
+  const uint32_t hm = (b3 << 8) - b3;
+  uint32_t vm = k == m.rs.nd - 1 ? m.rs.mask_last : ~0u;
+  if (FIRST) vm &= m.rs.mask_first;
+  const uint32_t f4 = ((__builtin_amdgcn_perm(kFlagHi1, kFlagHi0, lo3) & hm) |
+                       (__builtin_amdgcn_perm(kFlagLo1, kFlagLo0, lo3) & ~hm)) & vm;
+  if ((f4 | mm.x | mm.y) == 0u) return;                  // common case: nothing but the counters
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int bb = (q + rot) & 3;
-          const int64_t bad = ad + bb;
-          if (bad >= b0 && bad < b1) {
-            const uint32_t code = (w >> (8 * bb)) & 15u;
-            if (code != 11u) {                                               // :187
-              const uint32_t slot = (uint32_t)(kMhlSlotMap >> (4 * code)) & 15u;
-              const int p = jp + (int)(bad - jo);
-              atomicAdd(&cb[slot * T + p], code == 9u ? 2u : 1u);            // :190-191
-              const uint32_t mi = ((bb & 2) ? mm.y : mm.x) >> (16 * (bb & 1)) & 0xFFFFu;
-              // the reference's counter slots 8/3/4 double as the sums (:190 vs :192-194)
-              atomicAdd(&sb[0 * T + p], (unsigned long long)jh_size + (code == 8u ? 1ull : 0ull));   // :192
-              const unsigned long long ni = (mi ? mhl_lut(mi, a.H) : 0ull) + (code == 3u ? 1ull : 0ull);
-              if (ni) atomicAdd(&sb[1 * T + p], ni);                         // :193
-              atomicAdd(&sb[2 * T + p], den_inc + (code == 4u ? 1ull : 0ull));   // :194
-            }
-          }
-        }
-      }
+  for (int j = 0; j < 4; j++) {
+    if (!((vm >> (8 * j)) & 1u)) continue;               // byte outside the slice (its m may be anything)
+    const uint32_t fl = (f4 >> (8 * j)) & 0xFFu;
+    const uint32_t mi = ((j & 2) ? mm.y : mm.x) >> (16 * (j & 1)) & 0xFFFFu;
+    const int p = m.pos0 + OFF + j;
+    unsigned long long *dh = L.dh + m.sidx * (MHL_T + 1) + p;
+    unsigned long long *dd = L.dd + m.sidx * (MHL_T + 1) + p;
+    if (fl & 1u) {                                       // '+'/'-': not counted, take the row's interval add back
+      atomicAdd(dh, 0ull - (unsigned long long)m.h); atomicAdd(dh + 1, (unsigned long long)m.h);
+      atomicAdd(dd, 0ull - sh); atomicAdd(dd + 1, sh);
+    } else {
+      const unsigned long long ni = (mi ? mhl_lut(mi, H) : 0ull) + ((fl & 2u) ? 1ull : 0ull);
+      if (ni) atomicAdd(L.num + m.sidx * MHL_T + p, ni);
+      if (fl & 4u) { atomicAdd(dd, 1ull); atomicAdd(dd + 1, 0ull - 1ull); }
+      if (fl & 8u) { atomicAdd(dh, 1ull); atomicAdd(dh + 1, 0ull - 1ull); }
     }
   }
+}
+
+template <int G, int WG>
+__device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td, const MhlLds &L) {
+  constexpr int R = 64 / G;
+  constexpr int NW = WG / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G;
+  int r = td.row_lo + wave * R + grp;
+  MhlSlice cur = mhl_row_slice<G>(a, td, r, sub, L.cnt);
+  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
+    uint32_t w[CX_UN];
+    uint2 mm[CX_UN];
+#pragma unroll
+    for (int u = 0; u < CX_UN; u++) {
+      const bool on = sub + u * G < cur.rs.nd;
+      w[u] = on ? cur.rs.src[u * G] : 0u;
+      mm[u] = on ? cur.msrc[u * G] : make_uint2(0u, 0u);
+    }
+    r += NW * R;
+    const MhlSlice nxt = mhl_row_slice<G>(a, td, r, sub, L.cnt);
+    const unsigned long long sh = mhl_lut(cur.h, a.H);   // S(h), :194
+    if (cur.rs.nd > 0 && sub == 0) {                     // the row's interval adds
+      unsigned long long *dh = L.dh + cur.sidx * (MHL_T + 1);
+      unsigned long long *dd = L.dd + cur.sidx * (MHL_T + 1);
+      atomicAdd(dh + cur.pf, (unsigned long long)cur.h); atomicAdd(dh + cur.pe, 0ull - (unsigned long long)cur.h);
+      atomicAdd(dd + cur.pf, sh); atomicAdd(dd + cur.pe, 0ull - sh);
+    }
+    if (sub < cur.rs.nd) mhl_add_dword<0, true>(w[0], mm[0], sub, cur, L, a.H, sh);
+    if (sub + G < cur.rs.nd) mhl_add_dword<4 * G, false>(w[1], mm[1], sub + G, cur, L, a.H, sh);
+    if (sub + 2 * G < cur.rs.nd) mhl_add_dword<8 * G, false>(w[2], mm[2], sub + 2 * G, cur, L, a.H, sh);
+    if (sub + 3 * G < cur.rs.nd) mhl_add_dword<12 * G, false>(w[3], mm[3], sub + 3 * G, cur, L, a.H, sh);
+    if (sub + 4 * G < cur.rs.nd) mhl_add_dword<16 * G, false>(w[4], mm[4], sub + 4 * G, cur, L, a.H, sh);
+    for (int k = sub + CX_UN * G; k < cur.rs.nd; k += G) {
+      MhlSlice t = cur;
+#pragma unroll
+      for (int j = 0; j < 4; j++) t.rs.dst[j] = cur.rs.dst[j] + 4 * (k - sub);
+      t.pos0 = cur.pos0 + 4 * (k - sub);
+      mhl_add_dword<0, false>(cur.rs.src[k - sub], cur.msrc[k - sub], k, t, L, a.H, sh);
+    }
+    cur = nxt;
+  }
+}
+
+// inclusive prefix sum of one u64 per thread over the workgroup (NW wavefronts)
+template <int NW>
+__device__ __forceinline__ unsigned long long block_incl_scan_u64(unsigned long long v, unsigned long long *s_w) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d, 64);
+    const uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, 64);
+    if (lane >= d) v += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane == 63) s_w[wave] = v;
+  __syncthreads();
+  unsigned long long add = 0;
+  for (int w = 0; w < wave; w++) add += s_w[w];
+  __syncthreads();
+  return v + add;
+}
+
+template <int G, int WG>
+__global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
+  constexpr int T = MHL_T;
+  constexpr int NW = WG / 64;
+  static_assert(WG >= T, "one position per thread in the emit phase");
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[2 * T + 4 * (T + 1)];
+  __shared__ unsigned long long s_w[NW];
+  __shared__ uint32_t s_scan[NW + 2];
+  MhlLds L;
+  L.cnt = cnt_raw + kCxGuard;
+  L.num = sums;
+  L.dh = sums + 2 * T;
+  L.dd = sums + 2 * T + 2 * (T + 1);
+  const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
+  for (int i = threadIdx.x; i < 2 * T + 4 * (T + 1); i += WG) sums[i] = 0ull;
+  __syncthreads();
+  const Tile td = a.tiles[tile];
+  mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
 
   // emit: one position per thread, '+' then '-'
   const int p = threadIdx.x;
+  const bool live = p < T;
   uint32_t key[2], cov[2];
   double len[2], lm[2];
   bool ok[2];
   int nr = 0;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
+    const unsigned long long hs = block_incl_scan_u64<NW>(live ? L.dh[s * (T + 1) + p] : 0ull, s_w);   // :192
+    const unsigned long long de = block_incl_scan_u64<NW>(live ? L.dd[s * (T + 1) + p] : 0ull, s_w);   // :194
     uint32_t c[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p];
+    for (int k = 0; k < 8; k++) c[k] = live ? L.cnt[(s * 8 + k) * T + p] : 0u;
     const uint32_t nH = c[SLOT_H] + c[SLOT_h], nX = c[SLOT_X] + c[SLOT_x], nZ = c[SLOT_Z] + c[SLOT_z];
     const uint32_t cv = c[SLOT_DOT] + c[SLOT_OTHER] + nH + nX + nZ;
     const uint32_t half = cv >> 1;                                           // :77
@@ -304,7 +488,7 @@ __global__ __launch_bounds__(MHL_WG) void k_mhl_tiles(MhlArgs a) {
     ok[s] = k != 0;
     key[s] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
     cov[s] = cc;                                                             // :90
-    const unsigned long long hs = sum64[(s * 3 + 0) * T + p], nu = sum64[(s * 3 + 1) * T + p], de = sum64[(s * 3 + 2) * T + p];
+    const unsigned long long nu = live ? L.num[s * T + p] : 0ull;
     len[s] = (double)hs / (double)(int)cc;                                   // :92
     lm[s] = (double)nu / (double)de;                                         // :93
     nr += k != 0;
@@ -388,6 +572,27 @@ static int ensure_mhl_pool(epi_batch *b, size_t rows) {
   return EPI_OK;
 }
 
+static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
+  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_mhl_tiles<8, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_mhl_tiles<16, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_mhl_tiles<32, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_mhl_tiles<64, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+  }
+}
+
+// lanes per row in the tile kernel (as pick_cx_group)
+static int pick_mhl_tile_group(int32_t max_len) {
+  const char *env = getenv("EPIHIP_MHL_TILE_GROUP");
+  if (env) { int g = atoi(env); if (g == 8 || g == 16 || g == 32 || g == 64) return g; }
+  const int slice = (max_len < MHL_T ? max_len : MHL_T) + 3;
+  const int nd = (slice + 3) / 4;
+  int g = 8;
+  while (g < 64 && g * CX_UN < nd) g <<= 1;
+  return g;
+}
+
 static int pick_mhl_group(int32_t max_len) {
   const char *env = getenv("EPIHIP_MHL_GROUP");
   if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
@@ -449,7 +654,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
 
   MhlArgs a;
-  a.xm = b->xm; a.m = b->mhl_m.as<uint16_t>(); a.off = b->off; a.start = b->start; a.strand = b->strand;
+  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = nullptr;
+  a.m = b->mhl_m.as<uint16_t>();
   a.rowinfo = b->mhl_h.as<int32_t>();
   a.tiles = b->tiles.as<Tile>();
   a.ctx_mask = ctx_mask; a.H = H;
@@ -457,6 +663,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
   uint32_t used_total[2] = {0, 0};
+  const int tg = pick_mhl_tile_group(st.max_len);
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_cov = b->pool_a.as<uint32_t>();
@@ -465,7 +672,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
     EPI_HIP(hipMemsetAsync(cursor, 0, 8, s));
     prof_begin("mhl_tiles", s);
-    hipLaunchKernelGGL(k_mhl_tiles, dim3((unsigned)nt), dim3(MHL_WG), 0, s, a);
+    launch_mhl_tiles(tg, nt, s, a);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));

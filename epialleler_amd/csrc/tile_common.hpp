@@ -1,0 +1,99 @@
+// Device code shared by the tile kernels (CX report and lMHL): the nibble LUT, the per-lane view of
+// a row's in-tile slice and the branch-free "four bases -> four LDS atomics" step.
+#pragma once
+#include "common.hpp"
+
+namespace epi {
+
+constexpr int CX_UN = 5;                      // dword loads a lane keeps in flight per row (the accumulate loops are written for 5)
+
+// nibble -> (counter slot, increment) as a 16-entry byte LUT for v_perm_b32: bits 0-2 = slot (see
+// enum in common.hpp), bits 4-5 = increment.
+//   code:     0    1    2    3    4    5    6    7 |   8    9   10   11 |  12   13   14   15
+//   byte:  0x11 0x11 0x12 0x11 0x11 0x11 0x14 0x16 | 0x11 0x21 0x13 0x00 | 0x10 0x11 0x15 0x17
+// increment 0 = skipped ('+'/'-' and filler, rcpp_cx_report.cpp:123: the atomic still issues but adds
+// nothing); 2 = nibble 9, which IS the reference's coverage slot and so counts twice (:126-127).
+constexpr uint32_t kLutLo0 = 0x11121111u, kLutLo1 = 0x16141111u, kLutHi0 = 0x00132111u, kLutHi1 = 0x17151110u;
+constexpr int kCxGuard = 4;               // dwords of LDS padding around the counters (see cx_add_dword)
+
+struct RowCols {                          // the batch columns a tile kernel reads
+  const uint8_t *xm;
+  const int64_t *off;
+  const int32_t *start, *strand, *pass;   // pass may be null (all TRUE)
+};
+
+struct RowSlice {                         // the part of one row that falls inside the tile, seen from one lane
+  const uint32_t *src;                    // this lane's first dword of the (dword-aligned) slice in xm
+  uint32_t *dst[4];                       // LDS cells (counter plane 0 of the row's strand) of the lane's first dword,
+                                          // in the order the lane walks its four bytes (see rot8)
+  int rot8;                               // 8 * byte rotation: sub-step j handles byte (j + rot) & 3
+  int nd;                                 // dwords in the slice (0 = nothing to do)
+  uint32_t lc4;                           // 0x08080808 when the read failed thresholding (lower-case, :118)
+  uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
+};
+
+template <int T, int G>
+__device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &td, int r, int sub, uint32_t *cnt) {
+  RowSlice m;
+  m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.lc4 = 0;
+  m.mask_first = ~0u; m.mask_last = ~0u;
+  if (r < td.row_hi) {
+    const int32_t st = a.start[r];
+    const int64_t o = a.off[r];
+    const int32_t len = (int32_t)((uint32_t)a.off[r + 1] - (uint32_t)o);   // < 2^31 (checked by k_row_stats)
+    const int32_t sd = a.strand[r];
+    const int32_t ps = a.pass ? a.pass[r] : 1;
+    // row index of the tile's first position; |rel| < Lmax + T for a candidate row
+    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)st);
+    const int32_t lo = rel > 0 ? rel : 0;
+    const int32_t hi = len < rel + T ? len : rel + T;
+    if (hi > lo) {
+      const int64_t b0 = o + lo;
+      const int32_t e_lo = (int32_t)b0 & 3;              // slice bytes are e in [e_lo, e_hi) from the aligned start
+      const int32_t e_hi = e_lo + (hi - lo);
+      m.nd = (e_hi + 3) >> 2;
+      m.src = reinterpret_cast<const uint32_t *>(a.xm + (b0 - e_lo)) + sub;
+      // Bank-conflict-free LDS atomics: at sub-step j a lane adds at position d + 4*sub' + ((j+rot)&3), i.e. in
+      // bank residue (d + j + rot) mod 4.  The 8 lanes of one "eighth" of a 32-lane half are 4 cells apart
+      // (8 banks of one residue); rot = eighth - d gives the four eighths the residues j, j+1, j+2, j+3 whatever
+      // rows (and row alignments d) they work on, so the 32 lanes always hit 32 different banks.
+      const int d = lo - rel - e_lo;
+      const int rot = ((int)((threadIdx.x & 31) >> 3) - d) & 3;
+      uint32_t *dst0 = cnt + (sd - 1) * 8 * T + d + 4 * sub;
+      m.rot8 = rot * 8;
+#pragma unroll
+      for (int j = 0; j < 4; j++) m.dst[j] = dst0 + ((j + rot) & 3);
+      m.lc4 = ps == 0 ? 0x08080808u : 0u;
+      m.mask_first = sub == 0 ? 0xFFFFFFFFu << (8 * e_lo) : ~0u;
+      m.mask_last = 0xFFFFFFFFu >> (8 * (4 * m.nd - e_hi));
+    }
+  }
+  return m;
+}
+
+// One dword (four bases) of a row into the LDS counters.  Every lane issues all four atomics: bytes
+// outside the slice and skipped codes are turned into "+0 on plane 0" by the masks, never branched
+// around.  A masked byte can sit up to 3 cells outside [0,T): the counters carry kCxGuard cells of
+// padding for that.  The byte order is rotated per lane (RowSlice::rot8) so that the 32 lanes of a half
+// wavefront always hit 32 different LDS banks.
+template <int T, int OFF, bool FIRST>
+__device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m) {
+  const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
+  const uint32_t lo3 = c4 & 0x07070707u;
+  const uint32_t b3 = (c4 >> 3) & 0x01010101u;
+  const uint32_t hm = (b3 << 8) - b3;                    // 0xFF where code >= 8
+  uint32_t s4 = (__builtin_amdgcn_perm(kLutHi1, kLutHi0, lo3) & hm) |
+                (__builtin_amdgcn_perm(kLutLo1, kLutLo0, lo3) & ~hm);
+  uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
+  if (FIRST) vm &= m.mask_first;
+  s4 &= vm;
+  s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
+#pragma unroll
+  for (int j = 0; j < 4; j++) {                          // OFF = 4 * (this dword's index - the lane's first index)
+    const uint32_t plane = (s4 >> (8 * j)) & 7u;
+    const uint32_t inc = (s4 >> (8 * j + 4)) & 3u;
+    atomicAdd(m.dst[j] + OFF + plane * T, inc);
+  }
+}
+
+}  // namespace epi
