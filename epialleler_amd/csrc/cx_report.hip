@@ -40,6 +40,12 @@ struct CxArgs {
   uint32_t *tile_nrow, *tile_base;
   int32_t *slab;                          // shared-tile counters [slot][16][T]
   int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit
+  // ultra-deep tiles (amplicon pile-ups) are set aside by k_cx_tiles and split over many workgroups
+  int heavy_rows;                         // a tile with more candidate rows than this is "heavy"
+  int heavy_chunk;                        // rows per work item of k_cx_heavy
+  uint32_t *heavy_count, *heavy_max;      // number of heavy tiles, largest candidate-row count among them
+  uint32_t *heavy_list;                   // their tile ids (order of discovery)
+  int32_t *heavy_slab;                    // [heavy tile][16][T] counters summed over the work items
 };
 
 // Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
@@ -174,10 +180,21 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
   uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
+  const Tile td = a.tiles[tile];
+  if (td.row_hi - td.row_lo > a.heavy_rows) {
+    // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
+    if (threadIdx.x == 0) {
+      const uint32_t h = atomicAdd(a.heavy_count, 1u);
+      a.heavy_list[h] = (uint32_t)tile;
+      atomicMax(a.heavy_max, (uint32_t)(td.row_hi - td.row_lo));
+      a.tile_nrow[tile] = 0;
+      a.tile_base[tile] = 0;
+    }
+    return;
+  }
   uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
   for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  const Tile td = a.tiles[tile];
   if (!(a.ablate & 1)) cx_accumulate<T, G, WG>(a, td, cnt);
   __syncthreads();
   if (td.slot >= 0) {
@@ -192,6 +209,45 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
   }
   if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   cx_emit<T, WG>(a, tile, cnt, s_scan);
+}
+
+// One chunk of the candidate rows of one heavy tile: LDS histogram as usual, then added into the tile's
+// dense counter slab in HBM (or straight into its shared slab slot when other ranks contribute too).
+template <int T, int G, int WG>
+__global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_heavy(CxArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[kCxPlanes * T + 2 * kCxGuard];
+  uint32_t *cnt = cnt_raw + kCxGuard;
+  const int tile = (int)a.heavy_list[blockIdx.y];
+  Tile td = a.tiles[tile];
+  const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
+  if (lo >= td.row_hi) return;
+  td.row_lo = lo;
+  if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
+  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  cx_accumulate<T, G, WG>(a, td, cnt);
+  __syncthreads();
+  int32_t *dst = td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+                              : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T);
+  for (int i = threadIdx.x; i < kCxPlanes * T; i += WG) {
+    const uint32_t v = cnt[i];
+    if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
+  }
+}
+
+// Majority rule + rows for the heavy tiles that are not shared with other ranks.
+template <int T>
+__global__ __launch_bounds__(CX_WG) void k_cx_emit_heavy(CxArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t cnt[kCxPlanes * T];
+  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  const int tile = (int)a.heavy_list[blockIdx.x];
+  const Tile td = a.tiles[tile];
+  if (td.slot >= 0) return;                                // emitted after the cross-rank reduce
+  const int32_t *src = a.heavy_slab + (int64_t)blockIdx.x * (kCxPlanes * T);
+  for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
+  __syncthreads();
+  cx_emit<T, CX_WG>(a, tile, cnt, s_scan);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
@@ -282,6 +338,30 @@ static void launch_cx_tiles(int T, int g, int nt, hipStream_t s, const CxArgs &a
   else { if (big) launch_cx_tiles_g<1024, 1024>(g, nt, s, a); else launch_cx_tiles_g<1024, 512>(g, nt, s, a); }
 }
 
+template <int T, int WG>
+static void launch_cx_heavy_g(int g, dim3 grid, hipStream_t s, const CxArgs &a) {
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, WG>), grid, dim3(WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, WG>), grid, dim3(WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, WG>), grid, dim3(WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, WG>), grid, dim3(WG), 0, s, a); break;
+  }
+}
+
+static void launch_cx_heavy(int T, int g, uint32_t nheavy, uint32_t nchunks, hipStream_t s, const CxArgs &a) {
+  const dim3 grid(nchunks, nheavy);
+  if (T == 512) {
+    launch_cx_heavy_g<512, 512>(g, grid, s, a);
+    hipLaunchKernelGGL((k_cx_emit_heavy<512>), dim3(nheavy), dim3(CX_WG), 0, s, a);
+  } else if (T == 2048) {
+    launch_cx_heavy_g<2048, 512>(g, grid, s, a);
+    hipLaunchKernelGGL((k_cx_emit_heavy<2048>), dim3(nheavy), dim3(CX_WG), 0, s, a);
+  } else {
+    launch_cx_heavy_g<1024, 1024>(g, grid, s, a);
+    hipLaunchKernelGGL((k_cx_emit_heavy<1024>), dim3(nheavy), dim3(CX_WG), 0, s, a);
+  }
+}
+
 static void launch_cx_emit_slab(int T, int nt, hipStream_t s, const CxArgs &a, const int32_t *owned) {
   if (T == 512) hipLaunchKernelGGL((k_cx_emit_slab<512>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
   else if (T == 2048) hipLaunchKernelGGL((k_cx_emit_slab<2048>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
@@ -339,6 +419,14 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.slab = b->d_slab;
   a.ablate = 0;
   if (const char *env = getenv("EPIHIP_CX_ABLATE")) a.ablate = atoi(env);
+  a.heavy_rows = 16384;
+  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
+  a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
+  EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
+  a.heavy_list = b->heavy_list.as<uint32_t>();
+  a.heavy_count = b->misc.as<uint32_t>() + 3;             // misc[3] = heavy tiles, misc[8] = their largest row count
+  a.heavy_max = b->misc.as<uint32_t>() + 8;
+  a.heavy_slab = nullptr;
   const int32_t nshared = (int32_t)b->shared_keys.size();
 
   // Shared tiles are emitted later (epi_batch_cx_finish_shared) into the same pool: keep room for them.
@@ -349,14 +437,31 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     a.pool_meth = b->pool_a.as<uint32_t>();
     a.pool_unmeth = b->pool_b.as<uint32_t>();
     a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
-    EPI_HIP(hipMemsetAsync(cursor, 0, 8, s));
+    EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
+    EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     prof_begin("cx_tiles", s);
     launch_cx_tiles(T, grp, nt, s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
-    // row offsets of the tiles are queued right away; {rows handed out, total rows} come back in one sync
+    // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    EPI_TRY(read_scalars(b, s, cursor, 8, used_total));
+    uint32_t host[8];
+    EPI_TRY(read_scalars(b, s, cursor, 32, host));         // misc[1..8]
+    if (host[2] > 0) {
+      // ultra-deep tiles were set aside: split each over ceil(rows/chunk) workgroups, reduce in HBM, emit, rescan
+      const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
+      EPI_TRY(b->heavy_slab.ensure((size_t)nheavy * kCxPlanes * T * 4));
+      a.heavy_slab = b->heavy_slab.as<int32_t>();
+      EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
+      prof_begin("cx_heavy", s);
+      launch_cx_heavy(T, grp, nheavy, nchunks, s, a);
+      prof_end("cx_heavy", s);
+      EPI_HIP(hipGetLastError());
+      EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+      EPI_TRY(read_scalars(b, s, cursor, 8, host));
+    }
+    used_total[0] = host[0];
+    used_total[1] = host[1];
     if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
     EPI_TRY(ensure_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once

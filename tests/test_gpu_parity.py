@@ -184,6 +184,19 @@ def test_deep_pileup_and_many_rnames(ea):
     check_all(ea, t, contexts=("CG",))
 
 
+def test_heavy_tiles_are_split(ea, monkeypatch):
+    """Ultra-deep tiles are set aside and split over many workgroups (k_cx_heavy); force that path on small data."""
+    monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "300")
+    rng = np.random.default_rng(31)
+    t = synth_np.random_templates(rng, 5000, 50, 400, 2, 60)            # two pile-ups, every tile heavy
+    check_all(ea, t, mhl=False, contexts=("CG", "CX"))
+    t = synth_np.random_templates(rng, 3000, 0, 700, 3, 9000)           # a mix of heavy and ordinary tiles
+    check_all(ea, t, mhl=False, contexts=("CG", "CX"))
+    check_all(ea, H.bam("amplicon010meth.bam"), mhl=False, contexts=("CG", "CX"))
+    monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "70")
+    check_all(ea, H.bam("amplicon010meth.bam"), mhl=False, contexts=("CG",))
+
+
 def test_long_reads(ea):
     rng = np.random.default_rng(29)
     t = synth_np.random_templates(rng, 40, 5000, 12000, 2, 30000, alphabet="......hhxzzZZZHXuU-")
