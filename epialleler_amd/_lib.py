@@ -26,6 +26,19 @@ class SynthParams(C.Structure):
                 ("gap_from", C.c_int32), ("gap_len", C.c_int32)]
 
 
+class BamOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("min_mapq", "min_baseq", "skip_duplicates", "skip_secondary", "skip_qcfail",
+                                         "skip_supplementary", "trim5", "trim3", "paired", "nthreads")]
+
+
+class Templates(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nbytes", C.c_int64), ("xm_capacity", C.c_int64), ("nrecs", C.c_int64),
+                ("xm", C.POINTER(C.c_uint8)), ("off", C.POINTER(C.c_int64)),
+                ("rname", C.POINTER(C.c_int32)), ("strand", C.POINTER(C.c_int32)), ("start", C.POINTER(C.c_int32)),
+                ("n_targets", C.c_int32), ("target_names", C.POINTER(C.c_char_p)),
+                ("paired", C.c_int32), ("pinned", C.c_int32)]
+
+
 class CxTable(C.Structure):
     _fields_ = [("nrow", C.c_int64)] + [(k, C.POINTER(C.c_int32)) for k in
                                         ("rname", "strand", "pos", "context", "meth", "unmeth")]
@@ -59,6 +72,8 @@ _SIGS = {
     "epi_get_xm_beta": (C.c_int, [_VP, _VP, _I64, _CS, _CS, _VP]),
     "epi_cx_report": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, _CS, C.POINTER(CxTable)]),
     "epi_mhl_report": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _CS, C.c_int, C.c_int, _F64, C.POINTER(MhlTable)]),
+    "epi_preprocess_bam": (C.c_int, [_CS, C.POINTER(BamOptions), C.POINTER(Templates)]),
+    "epi_templates_free": (None, [C.POINTER(Templates)]),
     "epi_engine_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "epi_engine_destroy": (None, [_VP]),
     "epi_engine_device": (C.c_int, [_VP]),

@@ -150,14 +150,36 @@ def _as_bam(bam):
     raise TypeError("expected a ProcessedBam (preprocessBam() result) or a dict of SoA columns")
 
 
-def preprocessBam(bam_file, **kwargs):
-    """R/preprocessBam.R:197-237.  An already preprocessed object is returned untouched (:226-235).
-    Reading BAM files is the host-side producer and not part of this engine yet."""
+def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, highest_prob=True,
+                  skip_duplicates=False, skip_secondary=True, skip_qcfail=True, skip_supplementary=True,
+                  trim=0, nthreads=1, verbose=False):
+    """R/preprocessBam.R:197-237.  An already preprocessed object is returned untouched (:226-235);
+    a path is decoded by the library's host-side producer (epi_preprocess_bam: zlib BGZF reader + the
+    reference's template packer), which yields the sorted SoA batch directly."""
     if isinstance(bam_file, (ProcessedBam, dict)):
         return _as_bam(bam_file)
-    raise NotImplementedError(
-        "BAM decoding stays on the host (HTSlib in the reference); pass a ProcessedBam built from "
-        "packed templates (ProcessedBam.from_arrays)")
+    import os
+    lib = _lib.load()
+    trim2 = (list(np.atleast_1d(trim)) * 2)[:2]                       # head(rep.int(trim, 2), 2)
+    opt = _lib.BamOptions(int(min_mapq), int(min_baseq), int(bool(skip_duplicates)), int(bool(skip_secondary)),
+                          int(bool(skip_qcfail)), int(bool(skip_supplementary)), int(trim2[0]), int(trim2[1]),
+                          -1 if paired is None else int(bool(paired)), max(int(nthreads), 1))
+    t = _lib.Templates()
+    rc = lib.epi_preprocess_bam(os.path.expanduser(str(bam_file)).encode(), C.byref(opt), C.byref(t))
+    if rc != _lib.EPI_OK:
+        msg = lib.epi_last_error().decode("utf-8", "replace")
+        raise ValueError(msg)                                         # stop(..., call.=FALSE) in the reference
+    try:
+        n = t.n
+        take = lambda ptr, k, dt: np.ctypeslib.as_array(ptr, shape=(max(k, 1),))[:k].astype(dt, copy=True)
+        levels = tuple(t.target_names[i].decode("latin1") for i in range(t.n_targets))
+        bam = ProcessedBam.from_arrays(take(t.xm, t.nbytes, np.uint8), take(t.off, n + 1, np.int64),
+                                       take(t.rname, n, np.int32), take(t.strand, n, np.int32),
+                                       take(t.start, n, np.int32), levels)
+        bam.nrecs, bam.npushed, bam.paired = int(t.nrecs), int(n), bool(t.paired)
+    finally:
+        lib.epi_templates_free(C.byref(t))
+    return bam
 
 
 # ---- Rcpp-level functions ----------------------------------------------------------------------

@@ -91,6 +91,35 @@ int epi_mhl_report(const uint8_t *xm, const int64_t *off, const int32_t *rname,
                    const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac,
                    epi_mhl_table *out);
 
+/* ---- host-side producer (preprocessBam) ----------------------------------
+ * BAM file -> packed templates sorted by (rname,start), as SoA host buffers (xm in
+ * pinned memory when a HIP device is usable).  Replaces rcpp_check_bam
+ * (src/rcpp_check_bam.cpp:19-60 + .checkBam, R/internal.R:75-128),
+ * rcpp_read_bam_paired / rcpp_read_bam_single (src/rcpp_read_bam.cpp:19-343) and the
+ * templid/sort step of .readBam (R/internal.R:154-199) for short-read XG/XM BAMs;
+ * BGZF/BAM are decoded with zlib only (no HTSlib).  Same defaults and error
+ * conditions as preprocessBam() (R/preprocessBam.R:197-237). */
+typedef struct {
+  int32_t min_mapq, min_baseq;
+  int32_t skip_duplicates, skip_secondary, skip_qcfail, skip_supplementary;   /* R defaults: 0,1,1,1 */
+  int32_t trim5, trim3;
+  int32_t paired;      /* -1 = detect as .checkBam does; 0/1 = expected endness (error if different) */
+  int32_t nthreads;    /* BGZF inflate threads (>=1) */
+} epi_bam_options;
+
+typedef struct {       /* library-owned; release with epi_templates_free */
+  int64_t n, nbytes, xm_capacity, nrecs;
+  uint8_t *xm;         /* [xm_capacity] packed SEQXM bytes of all templates in row order, 0xFB padded */
+  int64_t *off;        /* [n+1] */
+  int32_t *rname, *strand, *start;   /* [n] R factor codes / 1-based start */
+  int32_t n_targets;
+  char **target_names; /* rname levels: all BAM header targets (src/rcpp_read_bam.cpp:173-179) */
+  int32_t paired, pinned;
+} epi_templates;
+
+int epi_preprocess_bam(const char *path, const epi_bam_options *opt /* NULL = R defaults */, epi_templates *out);
+void epi_templates_free(epi_templates *t);
+
 /* ---- resident API -------------------------------------------------------- */
 
 typedef struct epi_engine epi_engine;   /* one per GPU: device id, streams, pinned staging */

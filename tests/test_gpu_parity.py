@@ -98,6 +98,20 @@ def test_capture_golden_numbers_through_gpu(ea):
     assert cx.levels["context"][6] == "CG" and cx.levels["strand"] == ("+", "-") and cx.levels["rname"] == tuple(b["levels"])
 
 
+def test_config1_bam_file_to_report(ea):
+    """BASELINE config 1 end to end: BAM on disk -> host packer -> HBM -> report (478 rows, 632 / 6449)."""
+    import os
+    path = os.path.join(H.GOLDEN, "bam", "amplicon010meth.bam")
+    rep = ea.generateCytosineReport(path)
+    assert [rep.nrow, int(rep["meth"].sum()), int(rep["unmeth"].sum())] == [478, 632, 6449]
+    t = H.bam("amplicon010meth.bam")
+    H.assert_reports_equal(dict(rep), orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], o_thr(t), "Z"))
+    m = ea.generateMhlReport(path, max_outofcontext_beta=1)
+    assert int(m["coverage"].sum()) == 7081
+    q = ea.generateCytosineReport(os.path.join(H.GOLDEN, "bam", "capture.bam"), min_mapq=30, min_baseq=20)
+    assert [q.nrow, int(q["meth"].sum()), int(q["unmeth"].sum())] == [15197, 4830, 15062]
+
+
 # ---- toy / edge cases ----------------------------------------------------------------------------
 
 def test_toys(ea):

@@ -75,8 +75,8 @@ def test_processed_bam_validation():
         ea.ProcessedBam.from_arrays(t["xm"][:-1], t["off"], t["rname"], t["strand"], t["start"])
     b = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"], levels=["chr1"])
     assert b.n == 2 and b.nbytes == 4 and ea.preprocessBam(b) is b
-    with pytest.raises(NotImplementedError):
-        ea.preprocessBam("some.bam")
+    with pytest.raises(ValueError):
+        ea.preprocessBam("some.bam")                      # "Unable to open BAM file for reading"
 
 
 def test_write_report_tsv(tmp_path):
