@@ -348,12 +348,11 @@ __device__ __forceinline__ void mhl_add_dword(uint32_t w, uint2 mm, int k, const
   cx_add_dword<MHL_T, OFF, FIRST>(w, k, m.rs);
   const uint32_t c4 = w & 0x0F0F0F0Fu;
   const uint32_t lo3 = c4 & 0x07070707u;
-  const uint32_t b3 = (c4 >> 3) & 0x01010101u;
-  const uint32_t hm = (b3 << 8) - b3;
+  const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
   uint32_t vm = k == m.rs.nd - 1 ? m.rs.mask_last : ~0u;
   if (FIRST) vm &= m.rs.mask_first;
-  const uint32_t f4 = ((__builtin_amdgcn_perm(kFlagHi1, kFlagHi0, lo3) & hm) |
-                       (__builtin_amdgcn_perm(kFlagLo1, kFlagLo0, lo3) & ~hm)) & vm;
+  const uint32_t f4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(kFlagHi1, kFlagHi0, lo3),
+                                            __builtin_amdgcn_perm(kFlagLo1, kFlagLo0, lo3), pick) & vm;
   if ((f4 | mm.x | mm.y) == 0u) return;                  // common case: nothing but the counters
 #pragma unroll
   for (int j = 0; j < 4; j++) {

@@ -40,13 +40,13 @@ template <int NCLS>
 __device__ __forceinline__ void acc_dword(uint32_t w, uint32_t mask, const Luts &L, uint32_t (&acc)[NCLS]) {
   const uint32_t v = w & 0x0F0F0F0Fu;                 // unpack_ctx_idx, four codes
   const uint32_t lo3 = v & 0x07070707u;
-  const uint32_t b3 = (v >> 3) & 0x01010101u;
-  const uint32_t hm = (b3 << 8) - b3;                 // 0xFF in bytes whose code >= 8
+  // per byte: take the codes-8..15 lookup when bit 3 of the code is set (selector j + 4*bit3)
+  const uint32_t pick = 0x03020100u | ((v >> 1) & 0x04040404u);
 #pragma unroll
   for (int k = 0; k < NCLS; k++) {
     const uint32_t rlo = __builtin_amdgcn_perm(L.c[k].lo1, L.c[k].lo0, lo3);
     const uint32_t rhi = __builtin_amdgcn_perm(L.c[k].hi1, L.c[k].hi0, lo3);
-    const uint32_t sel = ((rhi & hm) | (rlo & ~hm)) & mask;
+    const uint32_t sel = __builtin_amdgcn_perm(rhi, rlo, pick) & mask;
     acc[k] = __builtin_amdgcn_sad_u8(sel, 0u, acc[k]);  // += sum of the four weight bytes
   }
 }

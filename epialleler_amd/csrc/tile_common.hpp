@@ -80,18 +80,21 @@ template <int T, int OFF, bool FIRST>
 __device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m) {
   const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
   const uint32_t lo3 = c4 & 0x07070707u;
-  const uint32_t b3 = (c4 >> 3) & 0x01010101u;
-  const uint32_t hm = (b3 << 8) - b3;                    // 0xFF where code >= 8
-  uint32_t s4 = (__builtin_amdgcn_perm(kLutHi1, kLutHi0, lo3) & hm) |
-                (__builtin_amdgcn_perm(kLutLo1, kLutLo0, lo3) & ~hm);
+  // 16-entry byte LUT = two v_perm lookups (codes 0-7 / 8-15) + a third v_perm that picks, per byte,
+  // the second result when bit 3 of the code is set (selector j + 4*bit3): no multiply, no masks
+  const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
+  uint32_t s4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(kLutHi1, kLutHi0, lo3),
+                                      __builtin_amdgcn_perm(kLutLo1, kLutLo0, lo3), pick);
   uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
   if (FIRST) vm &= m.mask_first;
   s4 &= vm;
   s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
 #pragma unroll
   for (int j = 0; j < 4; j++) {                          // OFF = 4 * (this dword's index - the lane's first index)
-    const uint32_t plane = (s4 >> (8 * j)) & 7u;
-    const uint32_t inc = (s4 >> (8 * j + 4)) & 3u;
+    uint32_t plane = __builtin_amdgcn_ubfe(s4, 8 * j, 3);
+    asm("" : "+v"(plane));                               // keep v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise re-derives
+                                                         // the address with shift + and + add: one more VALU per base)
+    const uint32_t inc = __builtin_amdgcn_ubfe(s4, 8 * j + 4, 2);
     atomicAdd(m.dst[j] + OFF + plane * T, inc);
   }
 }
