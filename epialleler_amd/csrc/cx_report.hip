@@ -23,6 +23,7 @@
 // then gives every tile its place in the final, ordered table (k_cx_gather).
 #include "common.hpp"
 #include "tile_common.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,6 +41,7 @@ struct CxArgs {
   uint32_t *tile_nrow, *tile_base;
   int32_t *slab;                          // shared-tile counters [slot][16][T]
   int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit
+  unsigned long long *diag;               // timing experiments only (EPIHIP_CX_DIAG): per-phase cycle sums of wave 0
   // ultra-deep tiles (amplicon pile-ups) are set aside by k_cx_tiles and split over many workgroups
   int heavy_rows;                         // a tile with more candidate rows than this is "heavy"
   int heavy_chunk;                        // rows per work item of k_cx_heavy
@@ -180,6 +182,8 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
   uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if (a.diag) t0 = __builtin_amdgcn_s_memtime();
   const Tile td = a.tiles[tile];
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
@@ -195,8 +199,11 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
   uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
   for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
+  if (a.diag) t1 = __builtin_amdgcn_s_memtime();
   if (!(a.ablate & 1)) cx_accumulate<T, G, WG>(a, td, cnt);
+  if (a.diag) t2 = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  if (a.diag) t3 = __builtin_amdgcn_s_memtime();
   if (td.slot >= 0) {
     // shared with another rank (or split over several work items): hand the raw counters over
     int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * T);
@@ -209,6 +216,15 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
   }
   if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   cx_emit<T, WG>(a, tile, cnt, s_scan);
+  if (a.diag && (threadIdx.x & 63) == 0) {      // diagnostic build only: where a wavefront's tile time goes
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    const int w = threadIdx.x >> 6;
+    if (w == 0 || w == WG / 64 - 1) {
+      unsigned long long *d = a.diag + (w == 0 ? 0 : 8);
+      atomicAdd(d + 0, t1 - t0); atomicAdd(d + 1, t2 - t1); atomicAdd(d + 2, t3 - t2); atomicAdd(d + 3, t4 - t3);
+      atomicAdd(d + 4, 1ull);
+    }
+  }
 }
 
 // One chunk of the candidate rows of one heavy tile: LDS histogram as usual, then added into the tile's
@@ -419,6 +435,12 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.slab = b->d_slab;
   a.ablate = 0;
   if (const char *env = getenv("EPIHIP_CX_ABLATE")) a.ablate = atoi(env);
+  a.diag = nullptr;
+  if (getenv("EPIHIP_CX_DIAG")) {
+    EPI_TRY(b->diag.ensure(256));
+    a.diag = b->diag.as<unsigned long long>();
+    EPI_HIP(hipMemsetAsync(a.diag, 0, 128, s));
+  }
   a.heavy_rows = 16384;
   if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
@@ -467,6 +489,15 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     EPI_TRY(ensure_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once
     if (nshared > 0)   // the rerun adds into the slab again
       EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * T * 4, s));
+  }
+  if (a.diag) {
+    unsigned long long h[16];
+    EPI_HIP(hipMemcpy(h, a.diag, 128, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 2; k++)
+      if (h[8 * k + 4])
+        fprintf(stderr, "[cx diag wave %s] tiles %llu  cycles/tile: head+clear %.0f  accumulate %.0f  barrier %.0f  emit %.0f\n",
+                k ? "last" : "0", h[8 * k + 4], (double)h[8 * k] / h[8 * k + 4], (double)h[8 * k + 1] / h[8 * k + 4],
+                (double)h[8 * k + 2] / h[8 * k + 4], (double)h[8 * k + 3] / h[8 * k + 4]);
   }
   if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
   b->last_kind = 1;
