@@ -91,7 +91,7 @@ struct epi_batch {
   // multi-GPU shared tiles
   std::vector<int64_t> shared_keys;
   std::vector<int32_t> shared_owned;
-  epi::DevBuf d_shared_keys, d_shared_owned;
+  epi::DevBuf d_shared_keys, d_shared_owned, d_slot_tile;
   int32_t *d_slab = nullptr;
 };
 

@@ -268,13 +268,14 @@ __global__ __launch_bounds__(CX_WG) void k_cx_emit_heavy(CxArgs a) {
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
 template <int T>
-__global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned, int ntiles) {
+__global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned,
+                                                        const int32_t *__restrict__ slot_tile) {
   __shared__ __attribute__((aligned(16))) uint32_t cnt[kCxPlanes * T];
   __shared__ uint32_t s_scan[CX_WG / 64 + 2];
-  const int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  if (!owned[blockIdx.x]) return;                          // one workgroup per shared slot
+  const int tile = slot_tile[blockIdx.x];
+  if (tile < 0) return;
   const Tile td = a.tiles[tile];
-  if (td.slot < 0 || !owned[td.slot]) return;
   const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * T);
   for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
   __syncthreads();
@@ -378,10 +379,10 @@ static void launch_cx_heavy(int T, int g, uint32_t nheavy, uint32_t nchunks, hip
   }
 }
 
-static void launch_cx_emit_slab(int T, int nt, hipStream_t s, const CxArgs &a, const int32_t *owned) {
-  if (T == 512) hipLaunchKernelGGL((k_cx_emit_slab<512>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
-  else if (T == 2048) hipLaunchKernelGGL((k_cx_emit_slab<2048>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
-  else hipLaunchKernelGGL((k_cx_emit_slab<1024>), dim3((unsigned)nt), dim3(CX_WG), 0, s, a, owned, nt);
+static void launch_cx_emit_slab(int T, int nshared, hipStream_t s, const CxArgs &a, const int32_t *owned, const int32_t *slot_tile) {
+  if (T == 512) hipLaunchKernelGGL((k_cx_emit_slab<512>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else if (T == 2048) hipLaunchKernelGGL((k_cx_emit_slab<2048>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else hipLaunchKernelGGL((k_cx_emit_slab<1024>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
 }
 
 static int ensure_pool(epi_batch *b, size_t rows) {
@@ -529,7 +530,8 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   a.pool_meth = b->pool_a.as<uint32_t>();
   a.pool_unmeth = b->pool_b.as<uint32_t>();
   a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
-  launch_cx_emit_slab(cx_tile_positions(), nt, s, a, b->d_shared_owned.as<int32_t>());
+  launch_cx_emit_slab(cx_tile_positions(), (int)b->shared_keys.size(), s, a, b->d_shared_owned.as<int32_t>(),
+                      b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   {
     uint32_t used = 0;   // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free

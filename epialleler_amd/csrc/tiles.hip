@@ -92,7 +92,8 @@ __device__ __forceinline__ int64_t gallop_rows(const int32_t *rname, const int32
 __global__ __launch_bounds__(256) void k_tile_fill(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                     int64_t n, const RowStats *__restrict__ st, int32_t sh,
                                                     const uint32_t *__restrict__ row_off, Tile *__restrict__ tiles,
-                                                    const int64_t *__restrict__ shared_keys, int32_t nshared) {
+                                                    const int64_t *__restrict__ shared_keys, int32_t nshared,
+                                                    int32_t *__restrict__ slot_tile) {
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (x >= n) return;
   const int32_t lmax = st->max_len > 0 ? st->max_len : 1;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(const int32_t *__restrict__ s
       const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
       int32_t a = 0, z = nshared;
       while (a < z) { int32_t m = (a + z) >> 1; if (shared_keys[m] < key) a = m + 1; else z = m; }
-      if (a < nshared && shared_keys[a] == key) td.slot = a;
+      if (a < nshared && shared_keys[a] == key) { td.slot = a; slot_tile[a] = (int32_t)(slot_base + (uint32_t)(t - lo)); }
     }
     tiles[slot_base + (uint32_t)(t - lo)] = td;
   }
@@ -159,8 +160,12 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   if (nt > 0x7FFFFFF0u) return fail(EPI_ERR_ARG, "too many tiles (%u)", nt);
   EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
   const int32_t nshared = (int32_t)b->shared_keys.size();
+  if (nshared > 0) {   // slot -> this rank's tile index (-1: this rank has no rows near that tile)
+    EPI_TRY(b->d_slot_tile.ensure((size_t)nshared * 4));
+    EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
+  }
   hipLaunchKernelGGL(k_tile_fill, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, d_st, sh, b->row_off.as<uint32_t>(),
-                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared);
+                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   *ntiles_out = (int32_t)nt;
   return EPI_OK;

@@ -1,0 +1,73 @@
+"""The sharded CX report with the real HIP engine: ranks are separate processes that share the one
+MI355X of the test box and exchange the shared-tile slab over gloo (RCCL refuses two ranks on one
+device, so the nccl backend itself first runs on a multi-GPU node).  The table gathered on rank 0 must
+equal the single-GPU table and the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+import synth_np
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case(name):
+    rng = np.random.default_rng(77)
+    if name == "wgs":
+        return synth_np.generate(n_total=9000, read_len=300, n_chr=3)
+    if name == "amplicon":
+        return synth_np.random_templates(rng, 4000, 100, 400, 1, 30)
+    return synth_np.random_templates(rng, 2500, 0, 3000, 3, 9000)       # long reads, 3 rnames
+
+
+def _worker(rank, world, port, name, outdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import epialleler_amd as ea
+    from epialleler_amd import distributed as D
+    t = _case(name)
+    n = t["off"].size - 1
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    off = t["off"][lo:hi + 1]
+    shard = ea.ProcessedBam.from_arrays(t["xm"][int(off[0]):int(off[-1])], off - off[0], t["rname"][lo:hi],
+                                        t["strand"][lo:hi], t["start"][lo:hi])
+    eng = D.HipShardEngine(shard)
+    for thr, rctx in ((True, "CG"), (False, "CX")):
+        rep = D.sharded_cytosine_report(eng, threshold_reads=thr, report_context=rctx, gather=True)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "%s_%s.npz" % (name, rctx)), **{k: v.cpu().numpy() for k, v in rep.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "wgs"), (3, "amplicon"), (2, "mixed")])
+def test_sharded_equals_oracle(tmp_path, world, name):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    t = _case(name)
+    c = H.CONTEXT_TO_BASES["CG"]
+    p = orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+    for thr, rctx, letters in ((True, "CG", "Z"), (False, "CX", "ZXH")):
+        want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p if thr else None, letters)
+        got = dict(np.load(os.path.join(str(tmp_path), "%s_%s.npz" % (name, rctx))))
+        H.assert_reports_equal(got, want)
