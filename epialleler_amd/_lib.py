@@ -83,6 +83,7 @@ _SIGS = {
     "epi_batch_nrows": (_I64, [_VP]),
     "epi_batch_threshold_reads_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _VP]),
     "epi_batch_get_xm_beta_dev": (C.c_int, [_VP, _CS, _CS, _VP, _VP]),
+    "epi_batch_match_target_dev": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "epi_batch_cx_report_dev": (C.c_int, [_VP, _VP, _CS, _VP, C.POINTER(_I64)]),
     "epi_batch_cx_fetch_dev": (C.c_int, [_VP, C.POINTER(_VP), _VP]),
     "epi_batch_cx_fetch_host": (C.c_int, [_VP, C.POINTER(_VP), _VP]),

@@ -154,6 +154,14 @@ int epi_batch_threshold_reads_dev(epi_batch *b, const char *ctx_meth, const char
 int epi_batch_get_xm_beta_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth,
                               double *d_beta_out, void *stream);
 
+/* rcpp_match_amplicon / rcpp_match_capture (src/rcpp_match_target.cpp:16-81; callers .getBedReport /
+ * .getBedEcdf, R/internal.R:529-604): first BED row a read matches, 1-based, or INT32_MIN (NA_integer_).
+ * bed_chr are rname factor codes; capture = 0: start or end within `param` (tolerance);
+ * capture = 1: overlap >= `param`. */
+int epi_batch_match_target_dev(epi_batch *b, const int32_t *d_bed_chr, const int32_t *d_bed_start,
+                               const int32_t *d_bed_end, int32_t nbed, int32_t capture, int32_t param,
+                               int32_t *d_match_out, void *stream);
+
 /* CX report in two steps so the caller can allocate the output columns:
  *  1) compute: tile index, LDS-histogram tile kernel, majority rule, ordered
  *     row offsets.  Synchronises `stream` (row count comes back to the host).
