@@ -78,7 +78,7 @@ struct epi_batch {
   epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e;
   epi::DevBuf misc;         // cursor etc.
   epi::DevBuf mhl_m, mhl_h; // per-byte stretch sizes, per-row haplotype info
-  epi::DevBuf heavy_list, heavy_slab;   // ultra-deep tiles: ids and dense counters
+  epi::DevBuf heavy_list, heavy_slab, heavy_sums;   // ultra-deep tiles: ids and dense counters (+ lMHL sums)
   epi::DevBuf diag;                     // timing experiments only
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
   size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)

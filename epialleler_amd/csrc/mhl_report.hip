@@ -287,9 +287,15 @@ struct MhlArgs {
   double *pool_len, *pool_lmhl;
   uint32_t pool_cap;
   uint32_t *cursor, *tile_nrow, *tile_base;
+  // ultra-deep tiles are set aside and split over many workgroups (as in the CX kernel)
+  int heavy_rows, heavy_chunk;
+  uint32_t *heavy_count, *heavy_max, *heavy_list;
+  uint32_t *heavy_cnt;                    // [heavy tile][16][T] counters
+  unsigned long long *heavy_sums;         // [heavy tile][2T + 4(T+1)] numerator sums and difference arrays
 };
 
 constexpr int MHL_T = kMhlTile;
+constexpr int MHL_NSUM = 2 * kMhlTile + 4 * (kMhlTile + 1);
 
 // nibble -> flags of the rarely taken per-byte path: 1 = '+'/'-' (skipped, :187), 2/4/8 = stray nibbles
 // 3/4/8, whose counter slot IS the numerator / denominator / haplotype-size sum in the reference (:190)
@@ -434,31 +440,13 @@ __device__ __forceinline__ unsigned long long block_incl_scan_u64(unsigned long 
   return v + add;
 }
 
-template <int G, int WG>
-__global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
+// Rule, prefix sums of the interval arrays, ordered compaction of one tile (one position per thread).
+template <int WG>
+__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, unsigned long long *s_w,
+                                         uint32_t *s_scan) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
-  static_assert(WG >= T, "one position per thread in the emit phase");
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
-  __shared__ __attribute__((aligned(16))) unsigned long long sums[2 * T + 4 * (T + 1)];
-  __shared__ unsigned long long s_w[NW];
-  __shared__ uint32_t s_scan[NW + 2];
-  MhlLds L;
-  L.cnt = cnt_raw + kCxGuard;
-  L.num = sums;
-  L.dh = sums + 2 * T;
-  L.dd = sums + 2 * T + 2 * (T + 1);
-  const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= ntiles) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
-  for (int i = threadIdx.x; i < 2 * T + 4 * (T + 1); i += WG) sums[i] = 0ull;
-  __syncthreads();
-  const Tile td = a.tiles[tile];
-  mhl_accumulate<G, WG>(a, td, L);
-  __syncthreads();
-
   // emit: one position per thread, '+' then '-'
   const int p = threadIdx.x;
   const bool live = p < T;
@@ -527,6 +515,92 @@ __global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
   }
 }
 
+template <int G, int WG>
+__global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
+  constexpr int T = MHL_T;
+  constexpr int NW = WG / 64;
+  static_assert(WG >= T, "one position per thread in the emit phase");
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  __shared__ unsigned long long s_w[NW];
+  __shared__ uint32_t s_scan[NW + 2];
+  MhlLds L;
+  L.cnt = cnt_raw + kCxGuard;
+  L.num = sums;
+  L.dh = sums + 2 * T;
+  L.dd = sums + 2 * T + 2 * (T + 1);
+  const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const Tile td = a.tiles[tile];
+  if (td.row_hi - td.row_lo > a.heavy_rows) {            // pile-up: k_mhl_heavy splits it by row chunks
+    if (threadIdx.x == 0) {
+      const uint32_t h = atomicAdd(a.heavy_count, 1u);
+      a.heavy_list[h] = (uint32_t)tile;
+      atomicMax(a.heavy_max, (uint32_t)(td.row_hi - td.row_lo));
+      a.tile_nrow[tile] = 0;
+      a.tile_base[tile] = 0;
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
+  __syncthreads();
+  mhl_accumulate<G, WG>(a, td, L);
+  __syncthreads();
+  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+}
+
+// One chunk of the candidate rows of one heavy tile -> added into that tile's slab in HBM.
+template <int G, int WG>
+__global__ __launch_bounds__(WG) void k_mhl_heavy(MhlArgs a) {
+  constexpr int T = MHL_T;
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  MhlLds L;
+  L.cnt = cnt_raw + kCxGuard;
+  L.num = sums;
+  L.dh = sums + 2 * T;
+  L.dd = sums + 2 * T + 2 * (T + 1);
+  const int tile = (int)a.heavy_list[blockIdx.y];
+  Tile td = a.tiles[tile];
+  const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
+  if (lo >= td.row_hi) return;
+  td.row_lo = lo;
+  if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
+  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
+  __syncthreads();
+  mhl_accumulate<G, WG>(a, td, L);
+  __syncthreads();
+  uint32_t *dc = a.heavy_cnt + (int64_t)blockIdx.y * (16 * T);
+  unsigned long long *ds = a.heavy_sums + (int64_t)blockIdx.y * MHL_NSUM;
+  for (int i = threadIdx.x; i < 16 * T; i += WG) { const uint32_t v = L.cnt[i]; if (v) atomicAdd(dc + i, v); }
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
+}
+
+template <int WG>
+__global__ __launch_bounds__(WG) void k_mhl_emit_heavy(MhlArgs a) {
+  constexpr int T = MHL_T;
+  constexpr int NW = WG / 64;
+  __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  __shared__ unsigned long long s_w[NW];
+  __shared__ uint32_t s_scan[NW + 2];
+  MhlLds L;
+  L.cnt = cnt;
+  L.num = sums;
+  L.dh = sums + 2 * T;
+  L.dd = sums + 2 * T + 2 * (T + 1);
+  const int tile = (int)a.heavy_list[blockIdx.x];
+  const uint32_t *sc = a.heavy_cnt + (int64_t)blockIdx.x * (16 * T);
+  const unsigned long long *ss = a.heavy_sums + (int64_t)blockIdx.x * MHL_NSUM;
+  for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
+  __syncthreads();
+  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+}
+
 __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
                                                      const uint32_t *__restrict__ tile_base, int32_t ntiles, int64_t nrow,
                                                      const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_cov,
@@ -579,6 +653,17 @@ static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
     case 32: hipLaunchKernelGGL((k_mhl_tiles<32, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
     default: hipLaunchKernelGGL((k_mhl_tiles<64, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
   }
+}
+
+static void launch_mhl_heavy(int g, uint32_t nheavy, uint32_t nchunks, hipStream_t s, const MhlArgs &a) {
+  const dim3 grid(nchunks, nheavy);
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_mhl_heavy<8, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_mhl_heavy<16, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_mhl_heavy<32, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_mhl_heavy<64, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
+  }
+  hipLaunchKernelGGL((k_mhl_emit_heavy<MHL_WG>), dim3(nheavy), dim3(MHL_WG), 0, s, a);
 }
 
 // lanes per row in the tile kernel (as pick_cx_group)
@@ -661,6 +746,15 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.cursor = cursor;
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
+  a.heavy_rows = 16384;
+  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
+  a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
+  EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
+  a.heavy_list = b->heavy_list.as<uint32_t>();
+  a.heavy_count = b->misc.as<uint32_t>() + 3;             // misc layout as in the CX report
+  a.heavy_max = b->misc.as<uint32_t>() + 8;
+  a.heavy_cnt = nullptr;
+  a.heavy_sums = nullptr;
   uint32_t used_total[2] = {0, 0};
   const int tg = pick_mhl_tile_group(st.max_len);
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -669,13 +763,32 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     a.pool_len = b->pool_d.as<double>();
     a.pool_lmhl = b->pool_e.as<double>();
     a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
-    EPI_HIP(hipMemsetAsync(cursor, 0, 8, s));
+    EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
+    EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     prof_begin("mhl_tiles", s);
     launch_mhl_tiles(tg, nt, s, a);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    EPI_TRY(read_scalars(b, s, cursor, 8, used_total));
+    uint32_t host[8];
+    EPI_TRY(read_scalars(b, s, cursor, 32, host));         // misc[1..8]
+    if (host[2] > 0) {                                     // pile-ups: split, reduce in HBM, emit, rescan
+      const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
+      EPI_TRY(b->heavy_slab.ensure((size_t)nheavy * 16 * MHL_T * 4));
+      EPI_TRY(b->heavy_sums.ensure((size_t)nheavy * MHL_NSUM * 8));
+      a.heavy_cnt = b->heavy_slab.as<uint32_t>();
+      a.heavy_sums = b->heavy_sums.as<unsigned long long>();
+      EPI_HIP(hipMemsetAsync(a.heavy_cnt, 0, (size_t)nheavy * 16 * MHL_T * 4, s));
+      EPI_HIP(hipMemsetAsync(a.heavy_sums, 0, (size_t)nheavy * MHL_NSUM * 8, s));
+      prof_begin("mhl_heavy", s);
+      launch_mhl_heavy(tg, nheavy, nchunks, s, a);
+      prof_end("mhl_heavy", s);
+      EPI_HIP(hipGetLastError());
+      EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+      EPI_TRY(read_scalars(b, s, cursor, 8, host));
+    }
+    used_total[0] = host[0];
+    used_total[1] = host[1];
     if (used_total[0] <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
     EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024));

@@ -203,12 +203,12 @@ def test_heavy_tiles_are_split(ea, monkeypatch):
     monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "300")
     rng = np.random.default_rng(31)
     t = synth_np.random_templates(rng, 5000, 50, 400, 2, 60)            # two pile-ups, every tile heavy
-    check_all(ea, t, mhl=False, contexts=("CG", "CX"))
+    check_all(ea, t, mhl=True, contexts=("CG", "CX"))
     t = synth_np.random_templates(rng, 3000, 0, 700, 3, 9000)           # a mix of heavy and ordinary tiles
-    check_all(ea, t, mhl=False, contexts=("CG", "CX"))
-    check_all(ea, H.bam("amplicon010meth.bam"), mhl=False, contexts=("CG", "CX"))
+    check_all(ea, t, mhl=True, contexts=("CG", "CX"))
+    check_all(ea, H.bam("amplicon010meth.bam"), mhl=True, contexts=("CG", "CX"))
     monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "70")
-    check_all(ea, H.bam("amplicon010meth.bam"), mhl=False, contexts=("CG",))
+    check_all(ea, H.bam("amplicon010meth.bam"), mhl=True, contexts=("CG",))
 
 
 def test_long_reads(ea):
