@@ -94,6 +94,11 @@ _SIGS = {
     "epi_batch_tile_key_range": (C.c_int, [_VP, _VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "epi_batch_cx_set_shared": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     "epi_batch_cx_finish_shared": (C.c_int, [_VP, _CS, _VP, C.POINTER(_I64)]),
+    "epi_mhl_tile_positions": (C.c_int, []),
+    "epi_mhl_slab_sums": (C.c_int, []),
+    "epi_batch_tile_key_range_for": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    "epi_batch_mhl_set_shared": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
+    "epi_batch_mhl_finish_shared": (C.c_int, [_VP, _VP, C.POINTER(_I64)]),
     "epi_synth_generate_dev": (C.c_int, [C.POINTER(SynthParams), _VP, _VP, _VP, _VP, _VP, _VP]),
     "epi_prof_enable": (None, [C.c_int]),
     "epi_prof_get": (C.c_int, [_CS, C.POINTER(_F64), C.POINTER(_I64)]),

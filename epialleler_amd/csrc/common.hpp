@@ -93,6 +93,9 @@ struct epi_batch {
   std::vector<int32_t> shared_owned;
   epi::DevBuf d_shared_keys, d_shared_owned, d_slot_tile;
   int32_t *d_slab = nullptr;
+  int32_t *d_mhl_cnt_slab = nullptr;     // lMHL shared tiles: counters and 64-bit sums
+  int64_t *d_mhl_sum_slab = nullptr;
+  uint32_t mhl_ctx_mask = 0;
 };
 
 namespace epi {

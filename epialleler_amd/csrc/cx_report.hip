@@ -558,6 +558,8 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
   b->shared_keys.assign(h_keys, h_keys + nshared);
   b->shared_owned.assign(h_owned, h_owned + nshared);
   b->d_slab = nshared > 0 ? d_slab : nullptr;
+  b->d_mhl_cnt_slab = nullptr;
+  b->d_mhl_sum_slab = nullptr;
   if (nshared > 0) {
     EPI_TRY(b->d_shared_keys.ensure((size_t)nshared * 8));
     EPI_TRY(b->d_shared_owned.ensure((size_t)nshared * 4));
@@ -568,11 +570,15 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
 }
 
 int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int64_t *last_key) {
+  return epi_batch_tile_key_range_for(b, cx_tile_positions(), stream, first_key, last_key);
+}
+
+int epi_batch_tile_key_range_for(epi_batch *b, int tile_positions, void *stream, int64_t *first_key, int64_t *last_key) {
   if (!b || !first_key || !last_key) return fail(EPI_ERR_ARG, "epi_batch_tile_key_range: NULL argument");
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   *first_key = 0; *last_key = -1;              // empty range
-  const int T = cx_tile_positions();
+  const int T = tile_positions;
   RowStats st;
   int32_t nt = 0;
   EPI_TRY(build_tiles(b, s, T, &st, &nt));

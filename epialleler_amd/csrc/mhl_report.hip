@@ -292,6 +292,9 @@ struct MhlArgs {
   uint32_t *heavy_count, *heavy_max, *heavy_list;
   uint32_t *heavy_cnt;                    // [heavy tile][16][T] counters
   unsigned long long *heavy_sums;         // [heavy tile][2T + 4(T+1)] numerator sums and difference arrays
+  // tiles shared with other ranks of a sharded run: same two slabs, indexed by shared slot
+  uint32_t *shared_cnt;
+  unsigned long long *shared_sums;
 };
 
 constexpr int MHL_T = kMhlTile;
@@ -548,6 +551,14 @@ __global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
+  if (td.slot >= 0) {                                    // shared with another rank: hand the raw sums over
+    uint32_t *dc = a.shared_cnt + (int64_t)td.slot * (16 * T);
+    unsigned long long *ds = a.shared_sums + (int64_t)td.slot * MHL_NSUM;
+    for (int i = threadIdx.x; i < 16 * T; i += WG) { const uint32_t v = L.cnt[i]; if (v) atomicAdd(dc + i, v); }
+    for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
+    if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+    return;
+  }
   mhl_emit<WG>(a, tile, L, s_w, s_scan);
 }
 
@@ -573,8 +584,8 @@ __global__ __launch_bounds__(WG) void k_mhl_heavy(MhlArgs a) {
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
-  uint32_t *dc = a.heavy_cnt + (int64_t)blockIdx.y * (16 * T);
-  unsigned long long *ds = a.heavy_sums + (int64_t)blockIdx.y * MHL_NSUM;
+  uint32_t *dc = td.slot >= 0 ? a.shared_cnt + (int64_t)td.slot * (16 * T) : a.heavy_cnt + (int64_t)blockIdx.y * (16 * T);
+  unsigned long long *ds = td.slot >= 0 ? a.shared_sums + (int64_t)td.slot * MHL_NSUM : a.heavy_sums + (int64_t)blockIdx.y * MHL_NSUM;
   for (int i = threadIdx.x; i < 16 * T; i += WG) { const uint32_t v = L.cnt[i]; if (v) atomicAdd(dc + i, v); }
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
 }
@@ -593,8 +604,35 @@ __global__ __launch_bounds__(WG) void k_mhl_emit_heavy(MhlArgs a) {
   L.dh = sums + 2 * T;
   L.dd = sums + 2 * T + 2 * (T + 1);
   const int tile = (int)a.heavy_list[blockIdx.x];
+  if (a.tiles[tile].slot >= 0) return;                   // emitted after the cross-rank reduce
   const uint32_t *sc = a.heavy_cnt + (int64_t)blockIdx.x * (16 * T);
   const unsigned long long *ss = a.heavy_sums + (int64_t)blockIdx.x * MHL_NSUM;
+  for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
+  __syncthreads();
+  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+}
+
+// Emits the shared tiles this rank owns from the (already cross-rank reduced) slabs: one workgroup per slot.
+template <int WG>
+__global__ __launch_bounds__(WG) void k_mhl_emit_slab(MhlArgs a, const int32_t *__restrict__ owned,
+                                                       const int32_t *__restrict__ slot_tile) {
+  constexpr int T = MHL_T;
+  constexpr int NW = WG / 64;
+  __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  __shared__ unsigned long long s_w[NW];
+  __shared__ uint32_t s_scan[NW + 2];
+  if (!owned[blockIdx.x]) return;
+  const int tile = slot_tile[blockIdx.x];
+  if (tile < 0) return;
+  MhlLds L;
+  L.cnt = cnt;
+  L.num = sums;
+  L.dh = sums + 2 * T;
+  L.dd = sums + 2 * T + 2 * (T + 1);
+  const uint32_t *sc = a.shared_cnt + (int64_t)blockIdx.x * (16 * T);
+  const unsigned long long *ss = a.shared_sums + (int64_t)blockIdx.x * MHL_NSUM;
   for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
   __syncthreads();
@@ -755,6 +793,12 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.heavy_max = b->misc.as<uint32_t>() + 8;
   a.heavy_cnt = nullptr;
   a.heavy_sums = nullptr;
+  a.shared_cnt = reinterpret_cast<uint32_t *>(b->d_mhl_cnt_slab);
+  a.shared_sums = reinterpret_cast<unsigned long long *>(b->d_mhl_sum_slab);
+  const int32_t nshared = (int32_t)b->shared_keys.size();
+  if (nshared > 0 && (!a.shared_cnt || !a.shared_sums)) return fail(EPI_ERR_STATE, "shared tiles set without lMHL slabs (use epi_batch_mhl_set_shared)");
+  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * MHL_T : 0;
+  b->mhl_ctx_mask = ctx_mask;
   uint32_t used_total[2] = {0, 0};
   const int tg = pick_mhl_tile_group(st.max_len);
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -789,13 +833,68 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     }
     used_total[0] = host[0];
     used_total[1] = host[1];
-    if (used_total[0] <= a.pool_cap) break;
+    if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024));
+    EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));
+    if (nshared > 0) {   // the rerun adds into the shared slabs again
+      EPI_HIP(hipMemsetAsync(a.shared_cnt, 0, (size_t)nshared * 16 * MHL_T * 4, s));
+      EPI_HIP(hipMemsetAsync(a.shared_sums, 0, (size_t)nshared * MHL_NSUM * 8, s));
+    }
   }
+  if (nshared > 0) { b->last_kind = 4; return EPI_OK; }     // caller continues with epi_batch_mhl_finish_shared
   b->last_kind = 2;
   b->last_nrow = used_total[1];
   *nrow_out = used_total[1];
+  return EPI_OK;
+}
+
+int epi_mhl_tile_positions(void) { return MHL_T; }
+int epi_mhl_slab_sums(void) { return MHL_NSUM; }
+
+int epi_batch_mhl_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
+                             int32_t *d_cnt_slab, int64_t *d_sum_slab) {
+  if (nshared > 0 && (!d_cnt_slab || !d_sum_slab)) return fail(EPI_ERR_ARG, "epi_batch_mhl_set_shared: NULL slab");
+  // same key/owner bookkeeping as the CX report (the slot of a tile is assigned when the tile table is built)
+  int32_t dummy = 0;
+  EPI_TRY(epi_batch_cx_set_shared(b, h_keys, h_owned, nshared, nshared > 0 ? &dummy : nullptr));
+  b->d_slab = nullptr;
+  b->d_mhl_cnt_slab = nshared > 0 ? d_cnt_slab : nullptr;
+  b->d_mhl_sum_slab = nshared > 0 ? d_sum_slab : nullptr;
+  return EPI_OK;
+}
+
+// Second half of a sharded lMHL report: the slabs have been sum-reduced across ranks.
+int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out) {
+  if (!b || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_mhl_finish_shared: NULL argument");
+  if (b->last_kind != 4) return fail(EPI_ERR_STATE, "epi_batch_mhl_finish_shared without a sharded epi_batch_mhl_report_dev");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = pick_stream(b, stream);
+  const int32_t nt = b->last_ntiles;
+  uint32_t *cursor = b->misc.as<uint32_t>() + 1;
+  MhlArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tiles = b->tiles.as<Tile>();
+  a.ctx_mask = b->mhl_ctx_mask;
+  a.cursor = cursor;
+  a.tile_nrow = b->tile_nrow.as<uint32_t>();
+  a.tile_base = b->tile_base.as<uint32_t>();
+  a.shared_cnt = reinterpret_cast<uint32_t *>(b->d_mhl_cnt_slab);
+  a.shared_sums = reinterpret_cast<unsigned long long *>(b->d_mhl_sum_slab);
+  a.pool_key = b->pool_key.as<uint32_t>();
+  a.pool_cov = b->pool_a.as<uint32_t>();
+  a.pool_len = b->pool_d.as<double>();
+  a.pool_lmhl = b->pool_e.as<double>();
+  a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
+  hipLaunchKernelGGL((k_mhl_emit_slab<MHL_WG>), dim3((unsigned)b->shared_keys.size()), dim3(MHL_WG), 0, s, a,
+                     b->d_shared_owned.as<int32_t>(), b->d_slot_tile.as<int32_t>());
+  EPI_HIP(hipGetLastError());
+  EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+  uint32_t ut[2] = {0, 0};
+  EPI_TRY(read_scalars(b, s, cursor, 8, ut));
+  if (ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded lMHL report");
+  b->last_kind = 2;
+  b->last_nrow = ut[1];
+  *nrow_out = ut[1];
   return EPI_OK;
 }
 

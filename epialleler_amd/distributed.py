@@ -75,18 +75,19 @@ class HipShardEngine:
         self.lib = _lib.load()
         self.device = torch.device("cuda", self.bam.device)
         self._slab = None
-        self._range = None
+        self._range = {}
 
     def tile_positions(self):
         return self.lib.epi_tile_positions()
 
-    def key_range(self):
-        # a property of the resident (immutable) shard and the tile grid: computed once
-        if self._range is None:
+    def key_range(self, kind="cx"):
+        # a property of the resident (immutable) shard and the tile grid: computed once per tile size
+        if kind not in self._range:
+            T = self.lib.epi_tile_positions() if kind == "cx" else self.lib.epi_mhl_tile_positions()
             a, b = C.c_int64(0), C.c_int64(-1)
-            _lib.check(self.lib.epi_batch_tile_key_range(self.h, _stream(self.bam.device), C.byref(a), C.byref(b)))
-            self._range = (a.value, b.value)
-        return self._range
+            _lib.check(self.lib.epi_batch_tile_key_range_for(self.h, T, _stream(self.bam.device), C.byref(a), C.byref(b)))
+            self._range[kind] = (a.value, b.value)
+        return self._range[kind]
 
     def threshold(self, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n, min_frac, max_oo):
         from .api import rcpp_threshold_reads
@@ -124,6 +125,116 @@ class HipShardEngine:
         # detach the shared-tile state so that later single-GPU calls on this batch emit every tile
         _lib.check(self.lib.epi_batch_cx_set_shared(self.h, None, None, 0, None))
         return cols
+
+
+    # ---- lMHL -----------------------------------------------------------------------------------
+    def mhl_accumulate(self, ctx, hmax, hmin, max_oo, keys, owned):
+        torch = self.torch
+        T, NS = self.lib.epi_mhl_tile_positions(), self.lib.epi_mhl_slab_sums()
+        n = max(keys.size, 1)
+        self._mcnt = torch.zeros(n * 16 * T, dtype=torch.int32, device=self.device)
+        self._msum = torch.zeros(n * NS, dtype=torch.int64, device=self.device)
+        keys = np.ascontiguousarray(keys, np.int64)
+        owned = np.ascontiguousarray(owned, np.int32)
+        _lib.check(self.lib.epi_batch_mhl_set_shared(
+            self.h, C.c_void_p(keys.ctypes.data) if keys.size else None,
+            C.c_void_p(owned.ctypes.data) if keys.size else None, int(keys.size),
+            C.c_void_p(self._mcnt.data_ptr()) if keys.size else None,
+            C.c_void_p(self._msum.data_ptr()) if keys.size else None))
+        self._nshared = int(keys.size)
+        nrow = C.c_int64(0)
+        _lib.check(self.lib.epi_batch_mhl_report_dev(self.h, _lib.enc(ctx), int(hmax), int(hmin), float(max_oo),
+                                                     _stream(self.bam.device), C.byref(nrow)))
+        self._nrow = nrow.value
+        return self._mcnt, self._msum
+
+    def mhl_finish(self):
+        torch = self.torch
+        nrow = C.c_int64(self._nrow)
+        if self._nshared:
+            _lib.check(self.lib.epi_batch_mhl_finish_shared(self.h, _stream(self.bam.device), C.byref(nrow)))
+        n = nrow.value
+        icols = torch.empty((5, n), dtype=torch.int32, device=self.device)
+        dcols = torch.empty((2, n), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(self.lib.epi_batch_mhl_fetch_dev(self.h, _ptr_array([icols[i] for i in range(5)]),
+                                                        _ptr_array([dcols[i] for i in range(2)]), _stream(self.bam.device)))
+        _lib.check(self.lib.epi_batch_mhl_set_shared(self.h, None, None, 0, None, None))
+        return icols, dcols
+
+
+def _exchange_ranges(engine, kind, group):
+    """all_gather of every rank's (first,last) tile key -> (ranges, world, rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, last = engine.key_range(kind) if kind != "cx" else engine.key_range()
+    if world > 1:
+        mine = torch.tensor([first, last], dtype=torch.int64, device=engine.device)
+        allr = [torch.empty(2, dtype=torch.int64, device=engine.device) for _ in range(world)]
+        dist.all_gather(allr, mine, group=group)
+        ranges = [tuple(int(v) for v in t.cpu().tolist()) for t in allr]
+    else:
+        ranges = [(first, last)]
+    return ranges, world, rank
+
+
+def _gather_rows(tensors, group, world, rank, dev):
+    """Concatenates [k, n_r] tensors of all ranks on rank 0, in rank order (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    cnt = torch.tensor([tensors[0].shape[1]], dtype=torch.int64, device=dev)
+    cnts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    cnts = [int(c.item()) for c in cnts]
+    if rank != 0:
+        if tensors[0].shape[1]:
+            for t in tensors:
+                dist.send(t.contiguous(), dst=0, group=group)
+        return None
+    outs = [torch.empty((t.shape[0], sum(cnts)), dtype=t.dtype, device=dev) for t in tensors]
+    for o, t in zip(outs, tensors):
+        o[:, :cnts[0]] = t
+    pos = cnts[0]
+    for r in range(1, world):
+        if cnts[r]:
+            for o in outs:
+                buf = torch.empty((o.shape[0], cnts[r]), dtype=o.dtype, device=dev)
+                dist.recv(buf, src=r, group=group)
+                o[:, pos:pos + cnts[r]] = buf
+            pos += cnts[r]
+    return outs
+
+
+def sharded_mhl_report(engine, ctx, hmax, hmin, max_ooctx_meth_frac, group=None, gather=True, levels=None):
+    """rcpp_mhl_report over row-range shards (same exchange as the CX table, on 512-position tiles; the
+    64-bit sums travel as int64 and add with wrap-around, which is what unsigned addition does)."""
+    import torch.distributed as dist
+    ranges, world, rank = _exchange_ranges(engine, "mhl", group)
+    keys, owner = shared_tile_keys(ranges)
+    owned = (owner == rank).astype(np.int32)
+    cnt_slab, sum_slab = engine.mhl_accumulate(ctx, hmax, hmin, max_ooctx_meth_frac, keys, owned)
+    if world > 1 and keys.size:
+        dist.all_reduce(cnt_slab, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(sum_slab, op=dist.ReduceOp.SUM, group=group)
+    icols, dcols = engine.mhl_finish()
+    names = ("rname", "strand", "pos", "context", "coverage", "length", "lmhl")
+    if gather and world > 1:
+        got = _gather_rows([icols, dcols], group, world, rank, engine.device)
+        if got is None:
+            return None
+        icols, dcols = got
+    cols = [icols[i] for i in range(5)] + [dcols[i] for i in range(2)]
+    return Report(dict(zip(names, cols)), levels)
+
+
+def sharded_mhl(engine, haplotype_context="CG", max_haplotype_window=0, min_haplotype_length=0,
+                max_outofcontext_beta=0.1, group=None, gather=True, levels=None):
+    """generateMhlReport() over shards (R/generateMhlReport.R:170-197)."""
+    c = CONTEXT_TO_BASES[haplotype_context]
+    return sharded_mhl_report(engine, c["ctx_meth"] + c["ctx_unmeth"], max_haplotype_window, min_haplotype_length,
+                              max_outofcontext_beta, group, gather, levels)
 
 
 def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None):

@@ -192,6 +192,16 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
  * (nrow_out = 0); all-reduce the slab, then finish: */
 int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int64_t *nrow_out);
 
+/* The same exchange for the lMHL table (tiles of epi_mhl_tile_positions() positions): shared tiles
+ * hand over their counters [nshared][16][T] (int32) and their numerator sums / interval arrays
+ * [nshared][epi_mhl_slab_sums()] (int64, wrap-around arithmetic); all-reduce both, then finish. */
+int epi_mhl_tile_positions(void);
+int epi_mhl_slab_sums(void);
+int epi_batch_tile_key_range_for(epi_batch *b, int tile_positions, void *stream, int64_t *first_key, int64_t *last_key);
+int epi_batch_mhl_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
+                             int32_t *d_cnt_slab, int64_t *d_sum_slab);
+int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out);
+
 /* ---- synthetic input (bench/tests; DESIGN.md "Synthetic workload") ------- */
 typedef struct {
   uint64_t seed;

@@ -22,7 +22,7 @@ class NumpyShardEngine:
     def tile_positions(self):
         return T
 
-    def key_range(self):
+    def key_range(self, kind="cx"):
         if self.n == 0:
             return 0, -1
         t = self.t

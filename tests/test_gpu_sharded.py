@@ -57,6 +57,10 @@ def _worker(rank, world, port, name, outdir):
         rep = D.sharded_cytosine_report(eng, threshold_reads=thr, report_context=rctx, gather=True)
         if rank == 0:
             np.savez(os.path.join(outdir, "%s_%s.npz" % (name, rctx)), **{k: v.cpu().numpy() for k, v in rep.items()})
+    for hmax in (0, 2):
+        rep = D.sharded_mhl(eng, max_haplotype_window=hmax, gather=True)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "%s_mhl%d.npz" % (name, hmax)), **{k: v.cpu().numpy() for k, v in rep.items()})
     dist.destroy_process_group()
 
 
@@ -71,3 +75,7 @@ def test_sharded_equals_oracle(tmp_path, world, name):
         want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p if thr else None, letters)
         got = dict(np.load(os.path.join(str(tmp_path), "%s_%s.npz" % (name, rctx))))
         H.assert_reports_equal(got, want)
+    for hmax in (0, 2):
+        want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, 0, 0.1)
+        got = dict(np.load(os.path.join(str(tmp_path), "%s_mhl%d.npz" % (name, hmax))))
+        H.assert_reports_equal(got, want, float_cols=("length", "lmhl"))
