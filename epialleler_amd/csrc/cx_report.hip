@@ -282,30 +282,32 @@ __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t 
   cx_emit<T, CX_WG>(a, tile, cnt, s_scan);
 }
 
-// Output row i -> its tile (binary search in the exclusive scan of tile row counts) -> decode.
+// One wavefront per tile copies the tile's rows from the pool to their place in the final table
+// (offset = exclusive scan of the tile row counts) and decodes them: contiguous reads, contiguous writes.
 __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
-                                                    const uint32_t *__restrict__ tile_base, int32_t ntiles, int64_t nrow,
-                                                    const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_meth,
-                                                    const uint32_t *__restrict__ pool_unmeth, int32_t *__restrict__ o_rname,
-                                                    int32_t *__restrict__ o_strand, int32_t *__restrict__ o_pos,
-                                                    int32_t *__restrict__ o_ctx, int32_t *__restrict__ o_meth,
-                                                    int32_t *__restrict__ o_unmeth) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nrow) return;
-  int32_t lo = 0, hi = ntiles;                 // last tile with tile_out[t] <= i
-  while (hi - lo > 1) {
-    const int32_t mid = (lo + hi) >> 1;
-    if ((int64_t)tile_out[mid] <= i) lo = mid; else hi = mid;
+                                                    const uint32_t *__restrict__ tile_nrow, const uint32_t *__restrict__ tile_base,
+                                                    int32_t ntiles, const uint32_t *__restrict__ pool_key,
+                                                    const uint32_t *__restrict__ pool_meth, const uint32_t *__restrict__ pool_unmeth,
+                                                    int32_t *__restrict__ o_rname, int32_t *__restrict__ o_strand,
+                                                    int32_t *__restrict__ o_pos, int32_t *__restrict__ o_ctx,
+                                                    int32_t *__restrict__ o_meth, int32_t *__restrict__ o_unmeth) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint32_t n = tile_nrow[tile];
+  if (n == 0) return;
+  const int lane = threadIdx.x & 63;
+  const Tile td = tiles[tile];
+  const uint32_t src0 = tile_base[tile], dst0 = tile_out[tile];
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint32_t key = pool_key[src0 + i];
+    const uint32_t o = dst0 + i;
+    o_rname[o] = td.rname;
+    o_strand[o] = 1 + (int32_t)((key >> 3) & 1u);
+    o_pos[o] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
+    o_ctx[o] = (int32_t)(key & 7u);
+    o_meth[o] = (int32_t)pool_meth[src0 + i];
+    o_unmeth[o] = (int32_t)pool_unmeth[src0 + i];
   }
-  const Tile td = tiles[lo];
-  const uint32_t src = tile_base[lo] + (uint32_t)(i - tile_out[lo]);
-  const uint32_t key = pool_key[src];
-  o_rname[i] = td.rname;
-  o_strand[i] = 1 + (int32_t)((key >> 3) & 1u);
-  o_pos[i] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
-  o_ctx[i] = (int32_t)(key & 7u);
-  o_meth[i] = (int32_t)pool_meth[src];
-  o_unmeth[i] = (int32_t)pool_unmeth[src];
 }
 
 // lanes per row: enough that CX_UN dwords per lane cover the longest in-tile slice
@@ -599,9 +601,9 @@ int epi_batch_cx_fetch_dev(epi_batch *b, int32_t *const d_cols[6], void *stream)
   for (int i = 0; i < 6; i++) if (!d_cols[i]) return fail(EPI_ERR_ARG, "epi_batch_cx_fetch_dev: NULL column");
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
-  const unsigned nb = (unsigned)((b->last_nrow + 255) / 256);
+  const unsigned nb = (unsigned)((b->last_ntiles + 3) / 4);
   hipLaunchKernelGGL(k_cx_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
-                     b->tile_base.as<uint32_t>(), b->last_ntiles, b->last_nrow, b->pool_key.as<uint32_t>(),
+                     b->tile_nrow.as<uint32_t>(), b->tile_base.as<uint32_t>(), b->last_ntiles, b->pool_key.as<uint32_t>(),
                      b->pool_a.as<uint32_t>(), b->pool_b.as<uint32_t>(), d_cols[0], d_cols[1], d_cols[2], d_cols[3],
                      d_cols[4], d_cols[5]);
   EPI_HIP(hipGetLastError());

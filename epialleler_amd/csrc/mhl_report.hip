@@ -639,31 +639,33 @@ __global__ __launch_bounds__(WG) void k_mhl_emit_slab(MhlArgs a, const int32_t *
   mhl_emit<WG>(a, tile, L, s_w, s_scan);
 }
 
+// one wavefront per tile: pool rows -> their place in the final table (see k_cx_gather)
 __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
-                                                     const uint32_t *__restrict__ tile_base, int32_t ntiles, int64_t nrow,
-                                                     const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_cov,
-                                                     const double *__restrict__ pool_len, const double *__restrict__ pool_lmhl,
-                                                     int32_t *__restrict__ o_rname, int32_t *__restrict__ o_strand,
-                                                     int32_t *__restrict__ o_pos, int32_t *__restrict__ o_ctx,
-                                                     int32_t *__restrict__ o_cov, double *__restrict__ o_len,
-                                                     double *__restrict__ o_lmhl) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nrow) return;
-  int32_t lo = 0, hi = ntiles;
-  while (hi - lo > 1) {
-    const int32_t mid = (lo + hi) >> 1;
-    if ((int64_t)tile_out[mid] <= i) lo = mid; else hi = mid;
+                                                     const uint32_t *__restrict__ tile_nrow, const uint32_t *__restrict__ tile_base,
+                                                     int32_t ntiles, const uint32_t *__restrict__ pool_key,
+                                                     const uint32_t *__restrict__ pool_cov, const double *__restrict__ pool_len,
+                                                     const double *__restrict__ pool_lmhl, int32_t *__restrict__ o_rname,
+                                                     int32_t *__restrict__ o_strand, int32_t *__restrict__ o_pos,
+                                                     int32_t *__restrict__ o_ctx, int32_t *__restrict__ o_cov,
+                                                     double *__restrict__ o_len, double *__restrict__ o_lmhl) {
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint32_t n = tile_nrow[tile];
+  if (n == 0) return;
+  const int lane = threadIdx.x & 63;
+  const Tile td = tiles[tile];
+  const uint32_t src0 = tile_base[tile], dst0 = tile_out[tile];
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint32_t key = pool_key[src0 + i];
+    const uint32_t o = dst0 + i;
+    o_rname[o] = td.rname;
+    o_strand[o] = 1 + (int32_t)((key >> 3) & 1u);
+    o_pos[o] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
+    o_ctx[o] = (int32_t)(key & 7u);
+    o_cov[o] = (int32_t)pool_cov[src0 + i];
+    o_len[o] = pool_len[src0 + i];
+    o_lmhl[o] = pool_lmhl[src0 + i];
   }
-  const Tile td = tiles[lo];
-  const uint32_t src = tile_base[lo] + (uint32_t)(i - tile_out[lo]);
-  const uint32_t key = pool_key[src];
-  o_rname[i] = td.rname;
-  o_strand[i] = 1 + (int32_t)((key >> 3) & 1u);
-  o_pos[i] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
-  o_ctx[i] = (int32_t)(key & 7u);
-  o_cov[i] = (int32_t)pool_cov[src];
-  o_len[i] = pool_len[src];
-  o_lmhl[i] = pool_lmhl[src];
 }
 
 static size_t mhl_pool_rows(const epi_batch *b) { return b->pool_cap < b->pool_cap2 ? b->pool_cap : b->pool_cap2; }
@@ -906,9 +908,9 @@ int epi_batch_mhl_fetch_dev(epi_batch *b, int32_t *const d_icols[5], double *con
   for (int i = 0; i < 2; i++) if (!d_dcols[i]) return fail(EPI_ERR_ARG, "epi_batch_mhl_fetch_dev: NULL column");
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
-  const unsigned nb = (unsigned)((b->last_nrow + 255) / 256);
+  const unsigned nb = (unsigned)((b->last_ntiles + 3) / 4);
   hipLaunchKernelGGL(k_mhl_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
-                     b->tile_base.as<uint32_t>(), b->last_ntiles, b->last_nrow, b->pool_key.as<uint32_t>(),
+                     b->tile_nrow.as<uint32_t>(), b->tile_base.as<uint32_t>(), b->last_ntiles, b->pool_key.as<uint32_t>(),
                      b->pool_a.as<uint32_t>(), b->pool_d.as<double>(), b->pool_e.as<double>(), d_icols[0], d_icols[1],
                      d_icols[2], d_icols[3], d_icols[4], d_dcols[0], d_dcols[1]);
   EPI_HIP(hipGetLastError());

@@ -16,7 +16,10 @@
 
 namespace epi {
 
-constexpr int PR_UN = 4;       // 16-byte loads a lane keeps in flight
+#ifndef EPI_PR_UN
+#define EPI_PR_UN 10
+#endif
+constexpr int PR_UN = EPI_PR_UN;   // 16-byte loads a lane keeps in flight
 
 struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // weight bytes for codes 0-3, 4-7, 8-11, 12-15
 struct Luts { ClassLut c[4]; };
@@ -140,11 +143,12 @@ __global__ __launch_bounds__(256) void k_per_read(const uint8_t *__restrict__ xm
 static int pick_group(const epi_batch *b) {
   const char *env = getenv("EPIHIP_GROUP");
   if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
-  // lanes per read: few enough that every lane streams >= 2*PR_UN chunks of its read
+  // lanes per read: just enough that PR_UN chunks per lane cover a typical read in one pass (measured
+  // fastest on PE150: 2 lanes x 10 chunks; one lane per read loses to uncoalesced access)
   const int64_t mean = b->n > 0 ? b->nbytes / b->n : 0;
   const int64_t chunks = mean / 16 + 2;
-  int g = 4;
-  while (g < 64 && (int64_t)g * PR_UN * 2 < chunks) g <<= 1;   // two passes of PR_UN loads per lane measured fastest
+  int g = 2;
+  while (g < 64 && (int64_t)g * PR_UN < chunks) g <<= 1;
   return g;
 }
 
