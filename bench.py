@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rows timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="rows timed on the CPU oracle (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="N>1: also send every rank's rows to rank 0 inside the timed step")
