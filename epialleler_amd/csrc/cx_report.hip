@@ -51,10 +51,19 @@ struct CxArgs {
 };
 
 // Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
-// (64/G rows per wavefront step); a lane keeps CX_UN dword loads of its row in flight and the next
+// (64/G rows per wavefront step); a lane keeps CX_NU dword loads of its row in flight and the next
 // step's row metadata is fetched before the current step's atomics are issued.  (A deeper software
 // pipeline -- bytes one step ahead, columns three -- measured slower: the kernel is issue-bound, not
 // latency-bound, once two workgroups share a CU.)
+// dwords u = U0..U1-1 of a lane's row slice (dword index sub + u*G), all already loaded
+template <int T, int G, int U0, int U1>
+__device__ __forceinline__ void cx_add_range(const uint32_t (&w)[CX_NU], int sub, const RowSlice &cur) {
+  if constexpr (U0 < U1) {
+    if (sub + U0 * G < cur.nd) cx_add_dword<T, 4 * G * U0, U0 == 0>(w[U0], sub + U0 * G, cur);
+    cx_add_range<T, G, U0 + 1, U1>(w, sub, cur);
+  }
+}
+
 template <int T, int G, int WG>
 __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
   constexpr int R = 64 / G;
@@ -64,20 +73,16 @@ __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, u
   int r = td.row_lo + wave * R + grp;
   RowSlice cur = cx_row_slice<T, G>(a.c, td, r, sub, cnt);
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
-    uint32_t w[CX_UN];
+    uint32_t w[CX_NU];                                    // every load of the slice is in flight before the first is used
 #pragma unroll
-    for (int u = 0; u < CX_UN; u++) {
+    for (int u = 0; u < CX_NU; u++) {
       const int k = sub + u * G;
       w[u] = k < cur.nd ? cur.src[u * G] : 0u;
     }
     r += NW * R;
     const RowSlice nxt = cx_row_slice<T, G>(a.c, td, r, sub, cnt);
-    if (sub < cur.nd) cx_add_dword<T, 0, true>(w[0], sub, cur);
-    if (sub + G < cur.nd) cx_add_dword<T, 4 * G, false>(w[1], sub + G, cur);
-    if (sub + 2 * G < cur.nd) cx_add_dword<T, 8 * G, false>(w[2], sub + 2 * G, cur);
-    if (sub + 3 * G < cur.nd) cx_add_dword<T, 12 * G, false>(w[3], sub + 3 * G, cur);
-    if (sub + 4 * G < cur.nd) cx_add_dword<T, 16 * G, false>(w[4], sub + 4 * G, cur);
-    for (int k = sub + CX_UN * G; k < cur.nd; k += G) {   // slices longer than CX_UN*G dwords (long reads, small G)
+    cx_add_range<T, G, 0, CX_NU>(w, sub, cur);
+    for (int k = sub + CX_NU * G; k < cur.nd; k += G) {   // slices longer than CX_NU*G dwords (EPIHIP_CX_GROUP overrides)
       RowSlice t = cur;
 #pragma unroll
       for (int j = 0; j < 4; j++) t.dst[j] = cur.dst[j] + 4 * (k - sub);
@@ -310,14 +315,14 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
   }
 }
 
-// lanes per row: enough that CX_UN dwords per lane cover the longest in-tile slice
+// lanes per row: enough that CX_NU dwords per lane cover the longest in-tile slice
 static int pick_cx_group(int32_t max_len, int T) {
   const char *env = getenv("EPIHIP_CX_GROUP");
   if (env) { int g = atoi(env); if (g == 8 || g == 16 || g == 32 || g == 64) return g; }
   const int slice = (max_len < T ? max_len : T) + 3;
   const int nd = (slice + 3) / 4;
   int g = 8;
-  while (g < 64 && g * CX_UN * 2 < nd) g <<= 1;   // up to two passes of CX_UN dwords per lane measured fastest
+  while (g < 64 && g * CX_NU < nd) g <<= 1;   // the whole slice in one round of CX_NU loads per lane
   return g;
 }
 

@@ -5,7 +5,11 @@
 
 namespace epi {
 
-constexpr int CX_UN = 5;                      // dword loads a lane keeps in flight per row (the accumulate loops are written for 5)
+constexpr int CX_UN = 5;                      // lMHL: dword loads a lane keeps in flight per row (its accumulate loop is written for 5)
+#ifndef EPI_CX_NU
+#define EPI_CX_NU 10
+#endif
+constexpr int CX_NU = EPI_CX_NU;              // CX: dword loads a lane keeps in flight per row
 
 // nibble -> (counter slot, increment) as a 16-entry byte LUT for v_perm_b32: bits 0-2 = slot (see
 // enum in common.hpp), bits 4-5 = increment.
