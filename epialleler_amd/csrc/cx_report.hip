@@ -10,9 +10,11 @@
 // Here a workgroup owns one tile of T (default 1024) consecutive positions (tiles.hip).
 // Its candidate rows are a contiguous row range; a group of G lanes takes a
 // row, streams the slice of the row that falls inside the tile with coalesced
-// dword loads (several in flight per lane) and adds every base into u32
-// counters in LDS ([strand][8 counters][T], 64 KiB) with ds_add_u32; lanes of a
-// group walk consecutive positions, so their atomics spread over the banks.
+// dword loads (all in flight before the first is used) and adds every base into
+// counters in LDS with ds_add_u32: two u16 counters per dword ([strand][4 pairs][T],
+// 32 KiB; tiles with more than 32767 candidate rows never get here, they are "heavy"),
+// or plain u32 [strand][8][T]; lanes of a group walk consecutive positions, so their
+// atomics spread over the banks.
 // Only eight counters per (pos,strand) are ever read by the rule: '.', H, h,
 // X, x, Z, z and "everything else that counts toward coverage" (U/u and any
 // other nibble; nibble 9 counts twice because the reference's coverage slot is
@@ -56,22 +58,22 @@ struct CxArgs {
 // pipeline -- bytes one step ahead, columns three -- measured slower: the kernel is issue-bound, not
 // latency-bound, once two workgroups share a CU.)
 // dwords u = U0..U1-1 of a lane's row slice (dword index sub + u*G), all already loaded
-template <int T, int G, int U0, int U1>
+template <int T, int G, int U0, int U1, bool PK>
 __device__ __forceinline__ void cx_add_range(const uint32_t (&w)[CX_NU], int sub, const RowSlice &cur) {
   if constexpr (U0 < U1) {
-    if (sub + U0 * G < cur.nd) cx_add_dword<T, 4 * G * U0, U0 == 0>(w[U0], sub + U0 * G, cur);
-    cx_add_range<T, G, U0 + 1, U1>(w, sub, cur);
+    if (sub + U0 * G < cur.nd) cx_add_dword<T, 4 * G * U0, U0 == 0, PK>(w[U0], sub + U0 * G, cur);
+    cx_add_range<T, G, U0 + 1, U1, PK>(w, sub, cur);
   }
 }
 
-template <int T, int G, int WG>
+template <int T, int G, int WG, bool PK>
 __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
   constexpr int R = 64 / G;
   constexpr int NW = WG / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   int r = td.row_lo + wave * R + grp;
-  RowSlice cur = cx_row_slice<T, G>(a.c, td, r, sub, cnt);
+  RowSlice cur = cx_row_slice<T, G, PK>(a.c, td, r, sub, cnt);
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
     uint32_t w[CX_NU];                                    // every load of the slice is in flight before the first is used
 #pragma unroll
@@ -80,13 +82,13 @@ __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, u
       w[u] = k < cur.nd ? cur.src[u * G] : 0u;
     }
     r += NW * R;
-    const RowSlice nxt = cx_row_slice<T, G>(a.c, td, r, sub, cnt);
-    cx_add_range<T, G, 0, CX_NU>(w, sub, cur);
+    const RowSlice nxt = cx_row_slice<T, G, PK>(a.c, td, r, sub, cnt);
+    cx_add_range<T, G, 0, CX_NU, PK>(w, sub, cur);
     for (int k = sub + CX_NU * G; k < cur.nd; k += G) {   // slices longer than CX_NU*G dwords (EPIHIP_CX_GROUP overrides)
       RowSlice t = cur;
 #pragma unroll
       for (int j = 0; j < 4; j++) t.dst[j] = cur.dst[j] + 4 * (k - sub);
-      cx_add_dword<T, 0, false>(cur.src[k - sub], k, t);
+      cx_add_dword<T, 0, false, PK>(cur.src[k - sub], k, t);
     }
     cur = nxt;
   }
@@ -108,7 +110,7 @@ __device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, u
 }
 
 // Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
-template <int T, int WG>
+template <int T, int WG, bool PK = false>
 __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
   constexpr int PPT = T / WG;                          // consecutive positions per thread
   static_assert(PPT == 1 || PPT == 2 || PPT == 4, "emit phase layout");
@@ -123,8 +125,17 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       uint32_t c[8];
+      if constexpr (PK) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
+        for (int k = 0; k < 4; k++) {
+          const uint32_t w = cnt[(s * 4 + k) * T + p0 + q];
+          c[2 * k] = w & 0xFFFFu;
+          c[2 * k + 1] = w >> 16;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
+      }
       uint32_t m = 0, u = 0;
       const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
       ok[q * 2 + s] = ctx != 0;
@@ -179,10 +190,38 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
   return (b & 7) * chunk + (b >> 3);
 }
 
-// two workgroups per CU: 64 KiB of LDS each, and at WG = 1024 the VGPR budget of 8 waves per SIMD (64)
-template <int T, int G, int WG>
-__global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_tiles(CxArgs a, int ntiles) {
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[kCxPlanes * T + 2 * kCxGuard];
+// LDS dwords of one tile's counters: u32 [strand][8][T], or packed u16 pairs [strand][4][T] (tile_common.hpp)
+template <int T, bool PK> constexpr int cx_lds_dwords() { return (PK ? 8 : kCxPlanes) * T; }
+// waves per SIMD the kernel is compiled for: as many workgroups per CU as LDS (160 KiB) and 2048 threads allow
+template <int T, int WG, bool PK> constexpr int cx_waves_per_simd() {
+  const int by_lds = (160 * 1024) / (cx_lds_dwords<T, PK>() * 4 + 256), by_thr = 2048 / WG;
+  const int wgs = by_lds < by_thr ? by_lds : by_thr;
+  return wgs * WG / 256;
+}
+
+// Adds a tile's LDS counters into its dense u32 slab [16][T] in HBM (shared tiles, heavy tiles).
+template <int T, int WG, bool PK>
+__device__ __forceinline__ void cx_dump_slab(const uint32_t *cnt, int32_t *slab) {
+  uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
+  for (int i = threadIdx.x; i < cx_lds_dwords<T, PK>(); i += WG) {
+    const uint32_t v = cnt[i];
+    if (!v) continue;
+    if constexpr (PK) {
+      const int pl = i / T, p = i % T;                      // pl = strand*4 + pair -> planes 2*pl (low half), 2*pl+1
+      if (v & 0xFFFFu) atomicAdd(dst + (2 * pl) * T + p, v & 0xFFFFu);
+      if (v >> 16) atomicAdd(dst + (2 * pl + 1) * T + p, v >> 16);
+    } else {
+      atomicAdd(dst + i, v);
+    }
+  }
+}
+
+// As many workgroups per CU as LDS and the 2048-thread limit allow (default: packed counters, 32 KiB, four
+// 512-thread workgroups); always 8 waves per SIMD, i.e. a VGPR budget of 64.
+template <int T, int G, int WG, bool PK>
+__global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_tiles(CxArgs a, int ntiles) {
+  constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
   __shared__ uint32_t s_scan[WG / 64 + 2];
   uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
@@ -202,25 +241,21 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
     return;
   }
   uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (a.diag) t1 = __builtin_amdgcn_s_memtime();
-  if (!(a.ablate & 1)) cx_accumulate<T, G, WG>(a, td, cnt);
+  if (!(a.ablate & 1)) cx_accumulate<T, G, WG, PK>(a, td, cnt);
   if (a.diag) t2 = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (a.diag) t3 = __builtin_amdgcn_s_memtime();
   if (td.slot >= 0) {
     // shared with another rank (or split over several work items): hand the raw counters over
-    int32_t *dst = a.slab + (int64_t)td.slot * (kCxPlanes * T);
-    for (int i = threadIdx.x; i < kCxPlanes * T; i += WG) {
-      const uint32_t v = cnt[i];
-      if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
-    }
+    cx_dump_slab<T, WG, PK>(cnt, a.slab + (int64_t)td.slot * (kCxPlanes * T));
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
   if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
-  cx_emit<T, WG>(a, tile, cnt, s_scan);
+  cx_emit<T, WG, PK>(a, tile, cnt, s_scan);
   if (a.diag && (threadIdx.x & 63) == 0) {      // diagnostic build only: where a wavefront's tile time goes
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
     const int w = threadIdx.x >> 6;
@@ -234,9 +269,10 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_ti
 
 // One chunk of the candidate rows of one heavy tile: LDS histogram as usual, then added into the tile's
 // dense counter slab in HBM (or straight into its shared slab slot when other ranks contribute too).
-template <int T, int G, int WG>
-__global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_heavy(CxArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[kCxPlanes * T + 2 * kCxGuard];
+template <int T, int G, int WG, bool PK>
+__global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_heavy(CxArgs a) {
+  constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
   uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = (int)a.heavy_list[blockIdx.y];
   Tile td = a.tiles[tile];
@@ -245,16 +281,12 @@ __global__ __launch_bounds__(WG, (T <= 1024 ? WG / 128 : WG / 256)) void k_cx_he
   td.row_lo = lo;
   if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
   uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < (kCxPlanes * T + 2 * kCxGuard) / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  cx_accumulate<T, G, WG>(a, td, cnt);
+  cx_accumulate<T, G, WG, PK>(a, td, cnt);
   __syncthreads();
-  int32_t *dst = td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
-                              : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T);
-  for (int i = threadIdx.x; i < kCxPlanes * T; i += WG) {
-    const uint32_t v = cnt[i];
-    if (v) atomicAdd(reinterpret_cast<uint32_t *>(dst) + i, v);
-  }
+  cx_dump_slab<T, WG, PK>(cnt, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+                                            : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
 }
 
 // Majority rule + rows for the heavy tiles that are not shared with other ranks.
@@ -326,6 +358,17 @@ static int pick_cx_group(int32_t max_len, int T) {
   return g;
 }
 
+// Counter layout: packed u16 pairs (32 KiB of LDS per 1024-position tile: four 512-thread workgroups per CU) unless
+// EPIHIP_CX_PACKED=0 (u32 counters, 64 KiB, two 1024-thread workgroups per CU: 1.52 vs 1.22 ms on config 2).
+static bool cx_packed() {
+  static int pk = -1;
+  if (pk < 0) {
+    pk = 1;
+    if (const char *env = getenv("EPIHIP_CX_PACKED")) pk = atoi(env) != 0;
+  }
+  return pk != 0;
+}
+
 int cx_tile_positions() {
   static int t = 0;
   if (!t) {
@@ -335,54 +378,58 @@ int cx_tile_positions() {
   return t;
 }
 
-template <int T, int WG>
-static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
-  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
-  switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, WG>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-  }
-}
-
 static int cx_workgroup_size() {
   static int wg = 0;
   if (!wg) {
-    wg = 1024;                                  // 2 x 16 wavefronts per CU measured fastest (profiles/)
-    if (const char *env = getenv("EPIHIP_CX_WG")) { const int v = atoi(env); if (v == 512 || v == 1024) wg = v; }
+    wg = cx_packed() ? 512 : 1024;              // 32 wavefronts per CU either way (4 x 8 or 2 x 16), measured fastest (profiles/)
+    if (const char *env = getenv("EPIHIP_CX_WG")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) wg = v; }
   }
   return wg;
 }
 
-static void launch_cx_tiles(int T, int g, int nt, hipStream_t s, const CxArgs &a) {
-  const bool big = cx_workgroup_size() == 1024;
-  if (T == 512) launch_cx_tiles_g<512, 512>(g, nt, s, a);
-  else if (T == 2048) { if (big) launch_cx_tiles_g<2048, 1024>(g, nt, s, a); else launch_cx_tiles_g<2048, 512>(g, nt, s, a); }
-  else { if (big) launch_cx_tiles_g<1024, 1024>(g, nt, s, a); else launch_cx_tiles_g<1024, 512>(g, nt, s, a); }
-}
-
-template <int T, int WG>
-static void launch_cx_heavy_g(int g, dim3 grid, hipStream_t s, const CxArgs &a) {
+template <int T, int WG, bool PK>
+static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
+  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, WG>), grid, dim3(WG), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, WG>), grid, dim3(WG), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, WG>), grid, dim3(WG), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, WG>), grid, dim3(WG), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
   }
 }
 
-static void launch_cx_heavy(int T, int g, uint32_t nheavy, uint32_t nchunks, hipStream_t s, const CxArgs &a) {
-  const dim3 grid(nchunks, nheavy);
-  if (T == 512) {
-    launch_cx_heavy_g<512, 512>(g, grid, s, a);
-    hipLaunchKernelGGL((k_cx_emit_heavy<512>), dim3(nheavy), dim3(CX_WG), 0, s, a);
-  } else if (T == 2048) {
-    launch_cx_heavy_g<2048, 512>(g, grid, s, a);
-    hipLaunchKernelGGL((k_cx_emit_heavy<2048>), dim3(nheavy), dim3(CX_WG), 0, s, a);
+template <int T, int WG, bool PK>
+static void launch_cx_heavy_g(int g, dim3 grid, hipStream_t s, const CxArgs &a) {
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, WG, PK>), grid, dim3(WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, WG, PK>), grid, dim3(WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, WG, PK>), grid, dim3(WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, WG, PK>), grid, dim3(WG), 0, s, a); break;
+  }
+}
+
+// (T, WG, layout) combinations that are built: the defaults (2048/1024/packed, 1024/1024/u32) and the ones the
+// EPIHIP_CX_* experiment switches reach.  heavy = false: k_cx_tiles over nt tiles; true: k_cx_heavy on `grid` + emit.
+template <int T, int WG, bool PK>
+static void launch_cx_variant(bool heavy, int g, int nt, dim3 grid, hipStream_t s, const CxArgs &a) {
+  if (!heavy) { launch_cx_tiles_g<T, WG, PK>(g, nt, s, a); return; }
+  launch_cx_heavy_g<T, WG, PK>(g, grid, s, a);
+  hipLaunchKernelGGL((k_cx_emit_heavy<T>), dim3(grid.y), dim3(CX_WG), 0, s, a);
+}
+
+static void launch_cx(bool heavy, int T, int g, int nt, dim3 grid, hipStream_t s, const CxArgs &a) {
+  const bool big = cx_workgroup_size() == 1024, pk = cx_packed();
+  if (pk && cx_workgroup_size() == 256) {
+    if (T == 512) launch_cx_variant<512, 256, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 256, true>(heavy, g, nt, grid, s, a);
+    return;
+  }
+  if (T == 512) { if (pk) launch_cx_variant<512, 512, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<512, 512, false>(heavy, g, nt, grid, s, a); }
+  else if (T == 2048) {
+    if (pk) { if (big) launch_cx_variant<2048, 1024, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<2048, 512, true>(heavy, g, nt, grid, s, a); }
+    else launch_cx_variant<2048, 1024, false>(heavy, g, nt, grid, s, a);
   } else {
-    launch_cx_heavy_g<1024, 1024>(g, grid, s, a);
-    hipLaunchKernelGGL((k_cx_emit_heavy<1024>), dim3(nheavy), dim3(CX_WG), 0, s, a);
+    if (pk) { if (big) launch_cx_variant<1024, 1024, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 512, true>(heavy, g, nt, grid, s, a); }
+    else { if (big) launch_cx_variant<1024, 1024, false>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 512, false>(heavy, g, nt, grid, s, a); }
   }
 }
 
@@ -451,6 +498,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   }
   a.heavy_rows = 16384;
   if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
+  if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // packed u16 counters: a base adds at most 2
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
   a.heavy_list = b->heavy_list.as<uint32_t>();
@@ -470,7 +518,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
     EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     prof_begin("cx_tiles", s);
-    launch_cx_tiles(T, grp, nt, s, a);
+    launch_cx(false, T, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
@@ -484,7 +532,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
       prof_begin("cx_heavy", s);
-      launch_cx_heavy(T, grp, nheavy, nchunks, s, a);
+      launch_cx(true, T, grp, nt, dim3(nchunks, nheavy), s, a);
       prof_end("cx_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));

@@ -18,6 +18,11 @@ constexpr int CX_NU = EPI_CX_NU;              // CX: dword loads a lane keeps in
 // increment 0 = skipped ('+'/'-' and filler, rcpp_cx_report.cpp:123: the atomic still issues but adds
 // nothing); 2 = nibble 9, which IS the reference's coverage slot and so counts twice (:126-127).
 constexpr uint32_t kLutLo0 = 0x11121111u, kLutLo1 = 0x16141111u, kLutHi0 = 0x00132111u, kLutHi1 = 0x17151110u;
+// Packed variant (two u16 counters per LDS dword: pair 0 = ('.', other), 1 = (H, h), 2 = (X, x), 3 = (Z, z); the
+// even slot in the low half): byte = [increment of the high half: bits 4-5][pair: bits 2-3][increment of the low half: bits 0-1]
+//   code:     0    1    2    3    4    5    6    7 |   8    9   10   11 |  12   13   14   15
+//   byte:  0x10 0x10 0x05 0x10 0x10 0x10 0x09 0x0D | 0x10 0x20 0x14 0x00 | 0x01 0x10 0x18 0x1C
+constexpr uint32_t kPkLo0 = 0x10051010u, kPkLo1 = 0x0D091010u, kPkHi0 = 0x00142010u, kPkHi1 = 0x1C181001u;
 constexpr int kCxGuard = 4;               // dwords of LDS padding around the counters (see cx_add_dword)
 
 struct RowCols {                          // the batch columns a tile kernel reads
@@ -36,7 +41,7 @@ struct RowSlice {                         // the part of one row that falls insi
   uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
 };
 
-template <int T, int G>
+template <int T, int G, bool PK = false>
 __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &td, int r, int sub, uint32_t *cnt) {
   RowSlice m;
   m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.lc4 = 0;
@@ -63,7 +68,7 @@ __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &t
       // rows (and row alignments d) they work on, so the 32 lanes always hit 32 different banks.
       const int d = lo - rel - e_lo;
       const int rot = ((int)((threadIdx.x & 31) >> 3) - d) & 3;
-      uint32_t *dst0 = cnt + (sd - 1) * 8 * T + d + 4 * sub;
+      uint32_t *dst0 = cnt + (sd - 1) * (PK ? 4 : 8) * T + d + 4 * sub;
       m.rot8 = rot * 8;
 #pragma unroll
       for (int j = 0; j < 4; j++) m.dst[j] = dst0 + ((j + rot) & 3);
@@ -80,19 +85,31 @@ __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &t
 // around.  A masked byte can sit up to 3 cells outside [0,T): the counters carry kCxGuard cells of
 // padding for that.  The byte order is rotated per lane (RowSlice::rot8) so that the 32 lanes of a half
 // wavefront always hit 32 different LDS banks.
-template <int T, int OFF, bool FIRST>
+template <int T, int OFF, bool FIRST, bool PK = false>
 __device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m) {
   const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
   const uint32_t lo3 = c4 & 0x07070707u;
   // 16-entry byte LUT = two v_perm lookups (codes 0-7 / 8-15) + a third v_perm that picks, per byte,
   // the second result when bit 3 of the code is set (selector j + 4*bit3): no multiply, no masks
   const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
-  uint32_t s4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(kLutHi1, kLutHi0, lo3),
-                                      __builtin_amdgcn_perm(kLutLo1, kLutLo0, lo3), pick);
+  uint32_t s4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(PK ? kPkHi1 : kLutHi1, PK ? kPkHi0 : kLutHi0, lo3),
+                                      __builtin_amdgcn_perm(PK ? kPkLo1 : kLutLo1, PK ? kPkLo0 : kLutLo0, lo3), pick);
   uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
   if (FIRST) vm &= m.mask_first;
   s4 &= vm;
   s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
+  if constexpr (PK) {
+    // value added to the pair's dword = low increment | high increment << 16, put together by one v_perm per base
+    const uint32_t lo4 = s4 & 0x03030303u, hi4 = (s4 >> 4) & 0x03030303u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t plane = __builtin_amdgcn_ubfe(s4, 8 * j + 2, 2);
+      asm("" : "+v"(plane));
+      const uint32_t val = __builtin_amdgcn_perm(hi4, lo4, 0x0C000C00u | ((4u + j) << 16) | (uint32_t)j);
+      atomicAdd(m.dst[j] + OFF + plane * T, val);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {                          // OFF = 4 * (this dword's index - the lane's first index)
     uint32_t plane = __builtin_amdgcn_ubfe(s4, 8 * j, 3);

@@ -1,0 +1,30 @@
+"""The CX tile kernel is built in several (tile size, workgroup size, counter layout) variants; the default
+is the measured-fastest one, the others stay reachable through EPIHIP_CX_* for A/B runs.  Every variant must
+give the oracle's table."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("env", [
+    {},                                                                  # default: packed u16 counters, T=1024, 512 threads
+    {"EPIHIP_CX_PACKED": "0"},                                           # u32 counters, 1024 threads
+    {"EPIHIP_CX_PACKED": "0", "EPIHIP_CX_TILE": "2048"},
+    {"EPIHIP_CX_TILE": "2048", "EPIHIP_CX_WG": "1024"},
+    {"EPIHIP_CX_TILE": "512", "EPIHIP_CX_WG": "256"},
+    {"EPIHIP_CX_GROUP": "16", "EPIHIP_HEAVY_ROWS": "500"},
+    {"EPIHIP_CX_PACKED": "0", "EPIHIP_CX_GROUP": "64", "EPIHIP_HEAVY_ROWS": "500"},
+])
+def test_cx_kernel_variants(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_variant_worker.py")], env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "variant ok" in r.stdout
