@@ -244,7 +244,7 @@ def rcpp_cx_report(df, pass_, ctx, as_device=False):
     _lib.check(lib.epi_batch_cx_report_dev(b, C.c_void_p(p.data_ptr()) if p is not None and bam.n else None,
                                            _lib.enc(ctx), _stream(bam.device), C.byref(nrow)))
     n = nrow.value
-    cols = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(6)]
+    cols = list(torch.empty((6, n), dtype=torch.int32, device=dev).unbind(0))   # one allocation: the GPU idles meanwhile
     if n:
         _lib.check(lib.epi_batch_cx_fetch_dev(b, _ptr_array(cols), _stream(bam.device)))
     names = ("rname", "strand", "pos", "context", "meth", "unmeth")
@@ -264,8 +264,8 @@ def rcpp_mhl_report(df, ctx, hmax, hmin, max_ooctx_meth_frac, as_device=False):
     _lib.check(lib.epi_batch_mhl_report_dev(b, _lib.enc(ctx), int(hmax), int(hmin), float(max_ooctx_meth_frac),
                                             _stream(bam.device), C.byref(nrow)))
     n = nrow.value
-    icols = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(5)]
-    dcols = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+    icols = list(torch.empty((5, n), dtype=torch.int32, device=dev).unbind(0))
+    dcols = list(torch.empty((2, n), dtype=torch.float64, device=dev).unbind(0))
     if n:
         _lib.check(lib.epi_batch_mhl_fetch_dev(b, _ptr_array(icols), _ptr_array(dcols), _stream(bam.device)))
     cols = icols + dcols

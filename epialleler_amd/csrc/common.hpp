@@ -62,6 +62,15 @@ struct epi_engine {
   int32_t *h_scalars = nullptr;       // pinned scratch for small D2H reads (64 x int64)
 };
 
+namespace epi {
+struct RowStats {          // filled by k_row_stats
+  int32_t max_len;
+  int32_t unsorted;        // !=0: some row violates (rname,start) order
+  int32_t bad_strand;      // !=0: strand not in {1,2}
+  int32_t bad_len;         // !=0: off not non-decreasing
+};
+}  // namespace epi
+
 struct epi_batch {
   epi_engine *eng = nullptr;
   int64_t n = 0, nbytes = 0;
@@ -72,8 +81,10 @@ struct epi_batch {
   epi::DevBuf own_xm, own_off, own_rname, own_strand, own_start;
 
   // reusable workspace
-  epi::DevBuf stats;        // RowStats
-  epi::DevBuf row_cnt, row_off, scan_tmp;
+  epi::DevBuf stats;        // RowStats of the batch (k_row_stats, queued once at creation)
+  bool stats_queued = false, stats_host = false;
+  epi::RowStats h_stats = {0, 0, 0, 0};   // host copy, fetched by the first report call (which raises the errors)
+  epi::DevBuf scan_tmp;
   epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
   epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e;
   epi::DevBuf misc;         // cursor etc.
@@ -100,21 +111,17 @@ struct epi_batch {
 
 namespace epi {
 
-struct RowStats {          // filled by k_row_stats
-  int32_t max_len;
-  int32_t unsorted;        // !=0: some row violates (rname,start) order
-  int32_t bad_strand;      // !=0: strand not in {1,2}
-  int32_t bad_len;         // !=0: off not non-decreasing
-};
-
 hipStream_t pick_stream(epi_batch *b, void *stream);
 int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst);  // sync D2H of a few bytes
 
 // util kernels (util.hip)
 int scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total,
                        DevBuf &tmp, hipStream_t s);
+int scan_block_sums_inplace(uint32_t *d_bsum, int64_t nb, uint32_t *d_total, hipStream_t s);
 
 // tile index (tiles.hip)
+// queue k_row_stats for a new batch (no sync, no error: per-read functions accept unsorted rows)
+int launch_row_stats(epi_batch *b, hipStream_t s);
 // row statistics (validated: errors for bad offsets/strands/unsorted rows) + tile table; one host sync
 int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out);
 

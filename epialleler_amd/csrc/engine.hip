@@ -226,6 +226,7 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const
   b->rname = b->own_rname.as<int32_t>();
   b->strand = b->own_strand.as<int32_t>();
   b->start = b->own_start.as<int32_t>();
+  if ((rc = launch_row_stats(b, nullptr))) { epi_batch_free(b); return rc; }
   *out = b;
   return EPI_OK;
 }
@@ -252,6 +253,11 @@ int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int
   b->rname = d_rname;
   b->strand = d_strand;
   b->start = d_start;
+  // length / order / strand statistics of the (from now on immutable) columns, queued on the null stream: the
+  // caller's columns must be complete as seen from that stream, as for every later call with stream = NULL
+  EPI_HIP(hipSetDevice(e->device));
+  const int rc = launch_row_stats(b, nullptr);
+  if (rc) { epi_batch_free(b); return rc; }
   *out = b;
   return EPI_OK;
 }
@@ -260,7 +266,7 @@ void epi_batch_free(epi_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
   DevBuf *bufs[] = {&b->own_xm, &b->own_off, &b->own_rname, &b->own_strand, &b->own_start, &b->stats,
-                    &b->row_cnt, &b->row_off, &b->scan_tmp, &b->tiles, &b->tile_nrow, &b->tile_base,
+                    &b->scan_tmp, &b->tiles, &b->tile_nrow, &b->tile_base,
                     &b->tile_out, &b->pool_key, &b->pool_a, &b->pool_b, &b->pool_c, &b->pool_d, &b->pool_e,
                     &b->misc, &b->mhl_m, &b->mhl_h, &b->d_shared_keys, &b->d_shared_owned, &b->heavy_list, &b->heavy_slab, &b->heavy_sums, &b->diag, &b->d_slot_tile};
   for (DevBuf *d : bufs) d->release();

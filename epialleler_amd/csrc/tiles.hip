@@ -62,17 +62,6 @@ __device__ __forceinline__ void row_tile_span(const int32_t *start, const int32_
   }
 }
 
-__global__ __launch_bounds__(256) void k_tile_counts(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
-                                                      int64_t n, const RowStats *__restrict__ st, int32_t sh,
-                                                      uint32_t *__restrict__ cnt) {
-  const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (x >= n) return;
-  const int32_t lmax = st->max_len > 0 ? st->max_len : 1;   // written by k_row_stats earlier on this stream
-  int64_t lo, b;
-  row_tile_span(start, rname, x, lmax, sh, &lo, &b);
-  cnt[x] = b >= lo ? (uint32_t)(b - lo + 1) : 0u;
-}
-
 // First row y >= x of rname r with start[y] >= s (rows are sorted): gallop forward from x, then bisect.
 // The rows of one tile are a few hundred at most, so this is ~2*log2(rows per tile) dependent loads.
 __device__ __forceinline__ int64_t gallop_rows(const int32_t *rname, const int32_t *start, int64_t n, int64_t x,
@@ -89,37 +78,91 @@ __device__ __forceinline__ int64_t gallop_rows(const int32_t *rname, const int32
   return lo;
 }
 
-__global__ __launch_bounds__(256) void k_tile_fill(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
-                                                    int64_t n, const RowStats *__restrict__ st, int32_t sh,
-                                                    const uint32_t *__restrict__ row_off, Tile *__restrict__ tiles,
-                                                    const int64_t *__restrict__ shared_keys, int32_t nshared,
-                                                    int32_t *__restrict__ slot_tile) {
-  const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (x >= n) return;
-  const int32_t lmax = st->max_len > 0 ? st->max_len : 1;
-  const int64_t T = 1LL << sh;
-  int64_t lo, b;
-  row_tile_span(start, rname, x, lmax, sh, &lo, &b);
-  if (b < lo) return;
-  const int32_t r = rname[x];
-  uint32_t slot_base = row_off[x];
-  int64_t from = x;
-  for (int64_t t = lo; t <= b; t++) {
-    Tile td;
-    td.pos0 = t * T - kPosBias;
-    td.rname = r;
-    // The row that creates a tile is the first one that can reach it (start >= pos0 - lmax + 1): it IS row_lo.
-    td.row_lo = (int32_t)x;
-    from = gallop_rows(rname, start, n, from, r, td.pos0 + T);   // first row starting beyond the tile
-    td.row_hi = (int32_t)from;
-    td.slot = -1;
-    if (nshared > 0) {
-      const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
-      int32_t a = 0, z = nshared;
-      while (a < z) { int32_t m = (a + z) >> 1; if (shared_keys[m] < key) a = m + 1; else z = m; }
-      if (a < nshared && shared_keys[a] == key) { td.slot = a; slot_tile[a] = (int32_t)(slot_base + (uint32_t)(t - lo)); }
+// The tile table in two passes over (start, rname) with nothing stored per row in between: pass A (FILL = false)
+// reduces the per-row tile counts of a block of TB_ROWS rows to one number; after a single-block scan of those
+// (k_scan_bsums) pass B (FILL = true) recomputes the counts, scans them inside the block and writes the tiles.
+constexpr int TB_THREADS = 256, TB_ITEMS = 8, TB_ROWS = TB_THREADS * TB_ITEMS;
+
+template <bool FILL>
+__global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
+                                                           int64_t n, int32_t lmax, int32_t sh, uint32_t *__restrict__ bsum,
+                                                           Tile *__restrict__ tiles, const int64_t *__restrict__ shared_keys,
+                                                           int32_t nshared, int32_t *__restrict__ slot_tile) {
+  __shared__ uint32_t s_tot[TB_ITEMS][TB_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * TB_ROWS + threadIdx.x;     // item i is row base + i*TB_THREADS: coalesced
+  uint32_t c[TB_ITEMS];
+  int64_t lo[TB_ITEMS];
+#pragma unroll
+  for (int i = 0; i < TB_ITEMS; i++) {
+    const int64_t x = base + (int64_t)i * TB_THREADS;
+    c[i] = 0; lo[i] = 0;
+    if (x < n) {
+      int64_t b;
+      row_tile_span(start, rname, x, lmax, sh, &lo[i], &b);
+      if (b >= lo[i]) c[i] = (uint32_t)(b - lo[i] + 1);
     }
-    tiles[slot_base + (uint32_t)(t - lo)] = td;
+  }
+  if (!FILL) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < TB_ITEMS; i++) t += c[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+    if (lane == 0) s_tot[0][wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+    return;
+  }
+  // exclusive scan in row order (item-major, then thread): wave scans per item, one pass over the 32 wave totals
+  uint32_t inc[TB_ITEMS];
+#pragma unroll
+  for (int i = 0; i < TB_ITEMS; i++) inc[i] = c[i];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int i = 0; i < TB_ITEMS; i++) {
+      const uint32_t t = __shfl_up(inc[i], d, 64);
+      if (lane >= d) inc[i] += t;
+    }
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < TB_ITEMS; i++) s_tot[i][wave] = inc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = bsum[blockIdx.x];                       // tiles created before this block (already scanned)
+    for (int i = 0; i < TB_ITEMS; i++)
+      for (int w = 0; w < TB_THREADS / 64; w++) { const uint32_t t = s_tot[i][w]; s_tot[i][w] = run; run += t; }
+  }
+  __syncthreads();
+  const int64_t T = 1LL << sh;
+#pragma unroll
+  for (int i = 0; i < TB_ITEMS; i++) {
+    if (c[i] == 0) continue;
+    const int64_t x = base + (int64_t)i * TB_THREADS;
+    const uint32_t slot_base = inc[i] - c[i] + s_tot[i][wave];
+    const int32_t r = rname[x];
+    int64_t from = x;
+    for (uint32_t k = 0; k < c[i]; k++) {
+      const int64_t t = lo[i] + k;
+      Tile td;
+      td.pos0 = t * T - kPosBias;
+      td.rname = r;
+      // The row that creates a tile is the first one that can reach it (start >= pos0 - lmax + 1): it IS row_lo.
+      td.row_lo = (int32_t)x;
+      from = gallop_rows(rname, start, n, from, r, td.pos0 + T);   // first row starting beyond the tile
+      td.row_hi = (int32_t)from;
+      td.slot = -1;
+      if (nshared > 0) {
+        const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
+        int32_t a = 0, z = nshared;
+        while (a < z) { int32_t m = (a + z) >> 1; if (shared_keys[m] < key) a = m + 1; else z = m; }
+        if (a < nshared && shared_keys[a] == key) { td.slot = a; slot_tile[a] = (int32_t)(slot_base + k); }
+      }
+      tiles[slot_base + k] = td;
+    }
   }
 }
 
@@ -129,34 +172,52 @@ static int log2_tile(int32_t T) {
   return sh;
 }
 
-// Row statistics + tile table with ONE host synchronisation: k_row_stats -> k_tile_counts (reads the maximum
-// length on the device) -> scan -> read back {stats, tile count} -> k_tile_fill.
+// Row statistics are a property of the (immutable) batch: queued once, when the batch is created.
+int launch_row_stats(epi_batch *b, hipStream_t s) {
+  EPI_TRY(b->stats.ensure(sizeof(RowStats)));
+  EPI_HIP(hipMemsetAsync(b->stats.p, 0, sizeof(RowStats), s));
+  if (b->n > 0) {
+    const unsigned nb = (unsigned)((b->n + 255) / 256);
+    hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, b->stats.as<RowStats>());
+    EPI_HIP(hipGetLastError());
+  }
+  b->stats_queued = true;
+  return EPI_OK;
+}
+
+// Validated row statistics (errors for bad offsets / strands / unsorted rows) + the tile table for tiles of T
+// positions.  One host synchronisation per call (the tile count); the statistics come back with the first one.
 int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *ntiles_out) {
   *ntiles_out = 0;
   memset(h, 0, sizeof(*h));
   if ((T & (T - 1)) != 0) return fail(EPI_ERR_ARG, "tile size must be a power of two");
   const int sh = log2_tile(T);
   EPI_TRY(b->misc.ensure(256));
-  // misc layout (u32): [0] tile count, [1] pool cursor, [2] output rows, [4..7] RowStats
+  // misc layout (u32): [0] tile count, [1] pool cursor, [2] output rows, [3] heavy tiles, [8] largest heavy tile
   uint32_t *d_misc = b->misc.as<uint32_t>();
-  RowStats *d_st = reinterpret_cast<RowStats *>(d_misc + 4);
-  EPI_HIP(hipMemsetAsync(d_misc, 0, 32, s));
+  EPI_HIP(hipMemsetAsync(d_misc, 0, 16, s));
   if (b->n == 0) return EPI_OK;
-  const unsigned nb = (unsigned)((b->n + 255) / 256);
-  EPI_TRY(b->row_cnt.ensure((size_t)b->n * 4));
-  EPI_TRY(b->row_off.ensure((size_t)b->n * 4));
-  hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, d_st);
-  hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, d_st, sh, b->row_cnt.as<uint32_t>());
-  EPI_TRY(scan_exclusive_u32(b->row_cnt.as<uint32_t>(), b->row_off.as<uint32_t>(), b->n, d_misc, b->scan_tmp, s));
-  uint32_t host[8];
-  EPI_TRY(read_scalars(b, s, d_misc, 32, host));
-  memcpy(h, host + 4, sizeof(RowStats));
+  if (!b->stats_host) {
+    if (!b->stats_queued) EPI_TRY(launch_row_stats(b, s));
+    EPI_TRY(read_scalars(b, s, b->stats.p, sizeof(RowStats), &b->h_stats));
+    b->stats_host = true;
+  }
+  *h = b->h_stats;
   if (h->bad_len) return fail(EPI_ERR_ARG, "offsets are not non-decreasing, or start+length exceeds int32");
   if (h->bad_strand) return fail(EPI_ERR_ARG, "strand values must be 1 ('+') or 2 ('-')");
   if (h->unsorted)
     return fail(EPI_ERR_UNSORTED, "rows are not sorted by (rname,start); the reference requires a pre-sorted dataset "
                                   "(src/rcpp_cx_report.cpp:19)");
-  const uint32_t nt = host[0];
+  const int32_t lmax = h->max_len > 0 ? h->max_len : 1;
+  const int64_t nb = (b->n + TB_ROWS - 1) / TB_ROWS;
+  EPI_TRY(b->scan_tmp.ensure((size_t)nb * 4));
+  uint32_t *bsum = b->scan_tmp.as<uint32_t>();
+  hipLaunchKernelGGL((k_tile_pass<false>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
+                     (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr);
+  EPI_HIP(hipGetLastError());
+  EPI_TRY(scan_block_sums_inplace(bsum, nb, d_misc, s));
+  uint32_t nt = 0;
+  EPI_TRY(read_scalars(b, s, d_misc, 4, &nt));
   if (nt > 0x7FFFFFF0u) return fail(EPI_ERR_ARG, "too many tiles (%u)", nt);
   EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
   const int32_t nshared = (int32_t)b->shared_keys.size();
@@ -164,7 +225,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
     EPI_TRY(b->d_slot_tile.ensure((size_t)nshared * 4));
     EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
   }
-  hipLaunchKernelGGL(k_tile_fill, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->n, d_st, sh, b->row_off.as<uint32_t>(),
+  hipLaunchKernelGGL((k_tile_pass<true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
                      b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   *ntiles_out = (int32_t)nt;

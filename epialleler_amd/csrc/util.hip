@@ -89,6 +89,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *__r
   }
 }
 
+// exclusive scan, in place, of nb block sums a caller produced itself (tiles.hip); total to *d_total
+int scan_block_sums_inplace(uint32_t *d_bsum, int64_t nb, uint32_t *d_total, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_THREADS), 0, s, d_bsum, nb, d_total);
+  EPI_HIP(hipGetLastError());
+  return EPI_OK;
+}
+
 int scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total, DevBuf &tmp,
                        hipStream_t s) {
   if (n <= 0) {
