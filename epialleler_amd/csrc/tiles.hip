@@ -5,7 +5,8 @@
 // row of that rname could reach it: tile(start) <= t <= tile(start + Lmax - 1).
 // Because rows are sorted by (rname,start), row x only has to create the tiles
 // its predecessor did not already reach -- a purely local count -- and one
-// exclusive scan over the rows turns the counts into tile slots.  This replaces
+// exclusive scan over the rows turns the counts into tile slots; a tile's last
+// candidate row is found the same way (row_tiles below).  This replaces
 // the reference's "flush the map when start > max_pos" windowing
 // (src/rcpp_cx_report.cpp:113) and the key sort of a sort+segmented-reduce
 // scheme: the input order already is the sort.
@@ -49,33 +50,37 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
   }
 }
 
-// tiles row x must create: (lo .. b], see header comment
-__device__ __forceinline__ void row_tile_span(const int32_t *start, const int32_t *rname, int64_t x, int32_t lmax,
-                                              int32_t sh, int64_t *lo, int64_t *b) {
-  const int64_t s = start[x];
-  const int64_t a = tile_of(s, sh);
-  *b = tile_of(s + lmax - 1, sh);
-  *lo = a;
-  if (x > 0 && rname[x - 1] == rname[x]) {
-    const int64_t bp = tile_of((int64_t)start[x - 1] + lmax - 1, sh);
-    if (bp + 1 > *lo) *lo = bp + 1;
-  }
-}
+// What row x contributes to the tile table, from its own and its predecessor's (rname, start) alone:
+//  * the tiles it creates, (lo .. b]: those it can reach that its predecessor could not (see header comment);
+//  * the tiles it closes, [hi_a .. hi_b]: row_hi of a tile (r,t) is the first row whose (rname, tile of start) lies
+//    beyond (r,t).  If x is such a row for anything, it is so exactly for the tiles from its predecessor's start
+//    tile up to the predecessor's reach (capped below x's own start tile within one rname) -- tiles the predecessor
+//    itself reaches, so they exist, and they are the LAST tiles created before x: their slots count back from the
+//    exclusive scan at x.  No search over rows is needed for either end of a tile's row range.
+struct RowTiles {
+  int64_t lo, b;          // creates tiles lo..b (b < lo: none)
+  int64_t hi_a, hi_b, bp; // closes tiles hi_a..hi_b (hi_b < hi_a: none); bp = predecessor's last reachable tile
+};
 
-// First row y >= x of rname r with start[y] >= s (rows are sorted): gallop forward from x, then bisect.
-// The rows of one tile are a few hundred at most, so this is ~2*log2(rows per tile) dependent loads.
-__device__ __forceinline__ int64_t gallop_rows(const int32_t *rname, const int32_t *start, int64_t n, int64_t x,
-                                               int32_t r, int64_t s) {
-  auto less = [&](int64_t y) { const int32_t rm = rname[y]; return rm < r || (rm == r && (int64_t)start[y] < s); };
-  int64_t lo = x, step = 64;
-  int64_t hi = x + step;
-  while (hi < n && less(hi)) { lo = hi + 1; step <<= 1; hi = lo + step; }
-  if (hi > n) hi = n;
-  while (lo < hi) {
-    const int64_t mid = lo + ((hi - lo) >> 1);
-    if (less(mid)) lo = mid + 1; else hi = mid;
+__device__ __forceinline__ RowTiles row_tiles(const int32_t *start, const int32_t *rname, int64_t x, int32_t lmax, int32_t sh) {
+  RowTiles rt;
+  const int64_t s = start[x];
+  const int64_t sx = tile_of(s, sh);
+  rt.b = tile_of(s + lmax - 1, sh);
+  rt.lo = sx;
+  rt.hi_a = 0; rt.hi_b = -1; rt.bp = 0;
+  if (x > 0) {
+    const int64_t sp = start[x - 1];
+    const int64_t tp = tile_of(sp, sh);
+    rt.bp = tile_of(sp + lmax - 1, sh);
+    if (rname[x - 1] == rname[x]) {
+      if (rt.bp + 1 > rt.lo) rt.lo = rt.bp + 1;
+      if (sx != tp) { rt.hi_a = tp; rt.hi_b = rt.bp < sx - 1 ? rt.bp : sx - 1; }
+    } else {
+      rt.hi_a = tp; rt.hi_b = rt.bp;
+    }
   }
-  return lo;
+  return rt;
 }
 
 // The tile table in two passes over (start, rname) with nothing stored per row in between: pass A (FILL = false)
@@ -92,15 +97,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * TB_ROWS + threadIdx.x;     // item i is row base + i*TB_THREADS: coalesced
   uint32_t c[TB_ITEMS];
-  int64_t lo[TB_ITEMS];
+  RowTiles rt[TB_ITEMS];
 #pragma unroll
   for (int i = 0; i < TB_ITEMS; i++) {
     const int64_t x = base + (int64_t)i * TB_THREADS;
-    c[i] = 0; lo[i] = 0;
+    c[i] = 0;
+    rt[i].lo = 0; rt[i].b = -1; rt[i].hi_a = 0; rt[i].hi_b = -1; rt[i].bp = 0;
     if (x < n) {
-      int64_t b;
-      row_tile_span(start, rname, x, lmax, sh, &lo[i], &b);
-      if (b >= lo[i]) c[i] = (uint32_t)(b - lo[i] + 1);
+      rt[i] = row_tiles(start, rname, x, lmax, sh);
+      if (rt[i].b >= rt[i].lo) c[i] = (uint32_t)(rt[i].b - rt[i].lo + 1);
     }
   }
   if (!FILL) {
@@ -140,28 +145,33 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
   const int64_t T = 1LL << sh;
 #pragma unroll
   for (int i = 0; i < TB_ITEMS; i++) {
-    if (c[i] == 0) continue;
     const int64_t x = base + (int64_t)i * TB_THREADS;
-    const uint32_t slot_base = inc[i] - c[i] + s_tot[i][wave];
-    const int32_t r = rname[x];
-    int64_t from = x;
-    for (uint32_t k = 0; k < c[i]; k++) {
-      const int64_t t = lo[i] + k;
-      Tile td;
-      td.pos0 = t * T - kPosBias;
-      td.rname = r;
-      // The row that creates a tile is the first one that can reach it (start >= pos0 - lmax + 1): it IS row_lo.
-      td.row_lo = (int32_t)x;
-      from = gallop_rows(rname, start, n, from, r, td.pos0 + T);   // first row starting beyond the tile
-      td.row_hi = (int32_t)from;
-      td.slot = -1;
-      if (nshared > 0) {
-        const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
-        int32_t a = 0, z = nshared;
-        while (a < z) { int32_t m = (a + z) >> 1; if (shared_keys[m] < key) a = m + 1; else z = m; }
-        if (a < nshared && shared_keys[a] == key) { td.slot = a; slot_tile[a] = (int32_t)(slot_base + k); }
+    if (x >= n) continue;
+    const uint32_t before = inc[i] - c[i] + s_tot[i][wave];      // tiles created by rows < x
+    for (int64_t t = rt[i].hi_a; t <= rt[i].hi_b; t++)            // tiles this row closes
+      tiles[(int64_t)before - 1 - (rt[i].bp - t)].row_hi = (int32_t)x;
+    if (c[i]) {
+      const int32_t r = rname[x];
+      for (uint32_t k = 0; k < c[i]; k++) {                       // tiles this row creates: it IS their row_lo
+        const int64_t t = rt[i].lo + k;                           // (the first row with start >= pos0 - lmax + 1)
+        Tile *td = tiles + before + k;
+        td->pos0 = t * T - kPosBias;
+        td->rname = r;
+        td->row_lo = (int32_t)x;
+        int32_t slot = -1;
+        if (nshared > 0) {
+          const int64_t key = ((int64_t)r << 32) | (int64_t)(uint32_t)t;
+          int32_t a = 0, z = nshared;
+          while (a < z) { int32_t m = (a + z) >> 1; if (shared_keys[m] < key) a = m + 1; else z = m; }
+          if (a < nshared && shared_keys[a] == key) { slot = a; slot_tile[a] = (int32_t)(before + k); }
+        }
+        td->slot = slot;
       }
-      tiles[slot_base + k] = td;
+    }
+    if (x == n - 1) {                                             // the end of the table closes what the last row reaches
+      const int64_t sx = tile_of(start[x], sh);
+      for (int64_t t = sx; t <= rt[i].b; t++)
+        tiles[(int64_t)before + c[i] - 1 - (rt[i].b - t)].row_hi = (int32_t)n;
     }
   }
 }
