@@ -88,7 +88,8 @@ struct epi_batch {
   epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
   epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e;
   epi::DevBuf misc;         // cursor etc.
-  epi::DevBuf mhl_m, mhl_h; // per-byte stretch sizes, per-row haplotype info
+  epi::DevBuf mhl_m, mhl_h, mhl_blk, mhl_cont, mhl_cur;   // lMHL pass 1: stretch records, per-read info, record table, block carries
+  size_t mhl_rec_cap = 0;   // records that fit mhl_m
   epi::DevBuf heavy_list, heavy_slab, heavy_sums;   // ultra-deep tiles: ids and dense counters (+ lMHL sums)
   epi::DevBuf diag;                     // timing experiments only
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b

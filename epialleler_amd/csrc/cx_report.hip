@@ -190,32 +190,6 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
   return (b & 7) * chunk + (b >> 3);
 }
 
-// LDS dwords of one tile's counters: u32 [strand][8][T], or packed u16 pairs [strand][4][T] (tile_common.hpp)
-template <int T, bool PK> constexpr int cx_lds_dwords() { return (PK ? 8 : kCxPlanes) * T; }
-// waves per SIMD the kernel is compiled for: as many workgroups per CU as LDS (160 KiB) and 2048 threads allow
-template <int T, int WG, bool PK> constexpr int cx_waves_per_simd() {
-  const int by_lds = (160 * 1024) / (cx_lds_dwords<T, PK>() * 4 + 256), by_thr = 2048 / WG;
-  const int wgs = by_lds < by_thr ? by_lds : by_thr;
-  return wgs * WG / 256;
-}
-
-// Adds a tile's LDS counters into its dense u32 slab [16][T] in HBM (shared tiles, heavy tiles).
-template <int T, int WG, bool PK>
-__device__ __forceinline__ void cx_dump_slab(const uint32_t *cnt, int32_t *slab) {
-  uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
-  for (int i = threadIdx.x; i < cx_lds_dwords<T, PK>(); i += WG) {
-    const uint32_t v = cnt[i];
-    if (!v) continue;
-    if constexpr (PK) {
-      const int pl = i / T, p = i % T;                      // pl = strand*4 + pair -> planes 2*pl (low half), 2*pl+1
-      if (v & 0xFFFFu) atomicAdd(dst + (2 * pl) * T + p, v & 0xFFFFu);
-      if (v >> 16) atomicAdd(dst + (2 * pl + 1) * T + p, v >> 16);
-    } else {
-      atomicAdd(dst + i, v);
-    }
-  }
-}
-
 // As many workgroups per CU as LDS and the 2048-thread limit allow (default: packed counters, 32 KiB, four
 // 512-thread workgroups); always 8 waves per SIMD, i.e. a VGPR budget of 64.
 template <int T, int G, int WG, bool PK>

@@ -4,20 +4,28 @@
 // Pass 1 of the reference (:158-182) is a sequential run-length walk over each
 // read: in-context bases are the haplotype; a maximal run of methylated
 // (upper-case) in-context bases, not interrupted by an unmethylated in-context
-// base, with m members gets num[i] = S(m) for EVERY byte between its first and
-// last member.  k_mhl_rows restates that as two segmented scans (segments are
-// cut by lower-case in-context bytes): A(i) = members at or before i, B(i) =
-// members at or after i, so byte i lies in a span iff A>0 and B>0 and
-// m = A + B - member(i).  A group of G lanes owns a read and walks it in blocks
-// of 16*G bytes (16 bytes per lane, sequential in registers; G-lane shuffles
-// scans across lanes; a carried state across blocks).  It stores m per byte
-// (u16) and per read the haplotype size h, or -1 when the read is skipped
-// (h < hmin or out-of-context beta too high, :176-179).
+// base ("cut"), with M members gives num[i] = S(M) to EVERY byte between its first
+// and last member.  Pass 2 (:185-195) adds, for every counted byte (code != 11)
+// of a kept read, its code counter, h (:192), num[i] (:193) and S(h) (:194) to
+// the byte's (pos,strand).  All three sums are constant over intervals of a read,
+// so nothing is stored per byte here:
 //
-// Pass 2 (:185-195) is the CX histogram plus three 64-bit sums per
-// (pos,strand): k_mhl_tiles is the CX tile kernel with ds_add_u64 for
-// sum(h), sum(S(m_i)), sum(S(h)) and 512-position tiles (56 KiB of LDS).
-// S(n) = n(n+1)(n+2)/6 is computed arithmetically (no 64K-entry table).
+//  k_mhl_rows    G lanes own a read, 32 bytes per lane.  Bit masks per lane (member,
+//                cut, skipped) come from a v_perm LUT; two segmented scans over the
+//                lanes give every lane the members of its open segment to the left
+//                and to the right; the spans are then found bit-parallel inside the
+//                lane (segmented fill of the member bits up to the next cut, both
+//                directions) and written as records (first, last, M), one per run of
+//                counted span bytes of a lane.  Reads with skipped bytes also get
+//                their counted runs as records (M = 0).  Per read: h, or -1 when the
+//                read is dropped (h < hmin or out-of-context beta too high, :176-179).
+//  k_mhl_tiles   the CX tile kernel (packed LDS histogram, tile_common.hpp) plus three
+//                u64 DIFFERENCE arrays per strand in LDS: a read adds +h/-h and
+//                +S(h)/-S(h) at the ends of its in-tile slice and +S(M)/-S(M) at the
+//                ends of every record that reaches into the tile; the emit phase
+//                prefix-sums them.  S(n) = n(n+1)(n+2)/6 is computed arithmetically
+//                (no 64K-entry table).  512-position tiles, 41 KiB of LDS, three
+//                workgroups per CU.
 #include "common.hpp"
 #include "tile_common.hpp"
 #include <stdlib.h>
@@ -26,6 +34,10 @@
 namespace epi {
 
 constexpr int MHL_WG = 512;
+constexpr int MHL_T = kMhlTile;
+constexpr int MHL_NSUM = 6 * (kMhlTile + 1);      // u64 per tile: difference arrays of sum S(M), sum h, sum S(h), two strands each
+constexpr int MHL_BLK_SHIFT = 11;                 // a block of the multi-block row kernel: 64 lanes x 32 bytes
+constexpr int MHL_REGIONS = 64, MHL_CUR_STRIDE = 32;   // record allocation cursors (u64 each, 256 B apart)
 
 __host__ __device__ __forceinline__ uint64_t nrS(uint64_t n) { return n < 2 ? n : (n * (n + 1) * (n + 2)) / 6; }   // :39-43
 // mhl_lookup[n] (:110-116) without the table; indices clamp at 65535 (the reference's table ends there)
@@ -34,7 +46,9 @@ __device__ __forceinline__ uint64_t mhl_lut(uint32_t n, uint32_t H) {
   return n < H ? nrS(n) : nrS(H);
 }
 
-struct Seg { uint32_t has; uint32_t cnt; };     // scan element: saw a cut? members since the last cut
+struct MhlRec { uint32_t first, last, m; };       // bytes [first,last] of the row; m = members of the stretch, 0 = counted run
+
+struct Seg { uint32_t has; uint32_t cnt; };       // scan element: saw a cut? members since the last cut
 __device__ __forceinline__ Seg seg_combine(Seg left, Seg right) {   // state after `left` then `right`
   Seg r;
   r.has = left.has | right.has;
@@ -42,245 +56,322 @@ __device__ __forceinline__ Seg seg_combine(Seg left, Seg right) {   // state aft
   return r;
 }
 
+// nibble -> flags: 1 member (in context, methylated), 2 cut (in context, unmethylated), 4 skipped ('+'/'-'/filler, :187),
+// 8 / 16 out-of-context methylated / unmethylated (:176-177).  Built on the host from the context string.
+struct MhlLut { uint32_t lo0, lo1, hi0, hi1; };
+
+struct RowsArgs {
+  const uint8_t *xm;
+  const int64_t *off;
+  int64_t n;
+  MhlLut lut;
+  int32_t hmin;
+  double max_oo;
+  int32_t *rowinfo;                       // [2n]: h or -1 (dropped), 1 if the read has skipped bytes
+  uint2 *blkrec;                          // (first record, records) per row, or per 2 KiB block of a row (multi)
+  MhlRec *recs;
+  uint32_t rec_cap;
+  unsigned long long *rec_cursor;         // MHL_REGIONS cursors, MHL_CUR_STRIDE apart: a workgroup takes its records from region
+                                          // blockIdx % MHL_REGIONS (one cursor for all serialises 3 M atomics: 25 ms); a cursor
+                                          // may run past its region's capacity rec_cap / MHL_REGIONS: the caller regrows and reruns
+  uint32_t *cont;                         // multi: members entering a block from the right
+};
+
+struct Chunk { uint32_t U, L, K, V, oom, oou; };
+
+// bit `bit` of the four bytes of f as a nibble
+__device__ __forceinline__ uint32_t plane_nibble(uint32_t f, int bit) {
+  uint32_t t = (f >> bit) & 0x01010101u;
+  t |= t >> 7;
+  t |= t >> 14;
+  return t & 0xFu;
+}
+
+// The 32 bytes at g0 (32-byte aligned) of the row [rs,re): per-byte bit masks.
+__device__ __forceinline__ Chunk mhl_chunk(const uint8_t *__restrict__ xm, int64_t g0, bool live, int64_t rs, int64_t re,
+                                           const MhlLut &lut) {
+  Chunk c = {0u, 0u, 0u, 0u, 0u, 0u};
+  if (!live) return c;
+  int64_t lo = rs - g0, hi = re - g0;
+  if (lo < 0) lo = 0;
+  if (hi > 32) hi = 32;
+  if (hi <= lo) return c;
+  const uint4 w0 = *reinterpret_cast<const uint4 *>(xm + g0);
+  uint4 w1 = make_uint4(0u, 0u, 0u, 0u);
+  if (g0 + 16 < re) w1 = *reinterpret_cast<const uint4 *>(xm + g0 + 16);
+  const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  c.V = (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+  uint32_t Mb = 0, Nb = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const uint32_t c4 = ww[d] & 0x0F0F0F0Fu;
+    const uint32_t lo3 = c4 & 0x07070707u;
+    const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
+    const uint32_t f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
+                                             __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+    c.U |= plane_nibble(f, 0) << (4 * d);
+    c.L |= plane_nibble(f, 1) << (4 * d);
+    c.K |= plane_nibble(f, 2) << (4 * d);
+    Mb |= plane_nibble(f, 3) << (4 * d);
+    Nb |= plane_nibble(f, 4) << (4 * d);
+  }
+  c.U &= c.V; c.L &= c.V; c.K &= c.V;
+  c.oom = __popc(Mb & c.V);
+  c.oou = __popc(Nb & c.V);
+  return c;
+}
+
+__device__ __forceinline__ uint32_t lead_members(const Chunk &c) {    // members before the first cut (all if none)
+  return __popc(c.U & (c.L ? ((c.L & (0u - c.L)) - 1u) : ~0u));
+}
+__device__ __forceinline__ uint32_t trail_members(const Chunk &c) {   // members after the last cut (all if none)
+  return __popc(c.U & (c.L ? ~((2u << (31 - __clz(c.L))) - 1u) : ~0u));
+}
+
+// Span bytes of the chunk: bytes that have a member of their stretch at or before them AND at or after them
+// (segmented fills of the member bits, stopped by cuts; `enter` / `cont` = members of the open segment in the lanes
+// to the left / right).  Counted span bytes are what pass 2 adds S(M) for.
+__device__ __forceinline__ uint32_t span_bits(const Chunk &c, uint32_t enter, uint32_t cont) {
+  const uint32_t nl = ~c.L;
+  uint32_t x = c.U | ((enter > 0u && !(c.L & 1u)) ? 1u : 0u);
+  uint32_t p = nl;
+  x |= (x << 1) & p; p &= p << 1;
+  x |= (x << 2) & p; p &= p << 2;
+  x |= (x << 4) & p; p &= p << 4;
+  x |= (x << 8) & p; p &= p << 8;
+  x |= (x << 16) & p;
+  uint32_t y = c.U | ((cont > 0u && !(c.L >> 31)) ? 0x80000000u : 0u);
+  uint32_t q = nl;
+  y |= (y >> 1) & q; q &= q >> 1;
+  y |= (y >> 2) & q; q &= q >> 2;
+  y |= (y >> 4) & q; q &= q >> 4;
+  y |= (y >> 8) & q; q &= q >> 8;
+  y |= (y >> 16) & q;
+  return x & y & nl & ~c.K & c.V;
+}
+
+__device__ __forceinline__ uint32_t run_count(uint32_t bits) { return __popc(bits & ~(bits << 1)); }
+
+// Writes one record per run of set bits of P (stretch pieces: m from the run's segment) or Q (counted runs, m = 0).
+__device__ __forceinline__ void write_runs(uint32_t bits, bool stretch, const Chunk &c, uint32_t enter, uint32_t cont,
+                                           uint32_t row_off0, MhlRec *__restrict__ out) {
+  while (bits) {
+    const int f = __ffs(bits) - 1;
+    const uint32_t t = ~(bits >> f);
+    const int e = t ? __ffs(t) - 1 : 32 - f;                 // run length
+    uint32_t m = 0;
+    if (stretch) {
+      const uint32_t lc = c.L & ((1u << f) - 1u);
+      const int a = lc ? 32 - __clz(lc) : 0;                  // segment = bits [a, b) between the surrounding cuts
+      const int end = f + e;
+      const uint32_t hc = end < 32 ? (c.L >> end) : 0u;
+      const int b = hc ? end + __ffs(hc) - 1 : 32;
+      const uint32_t segmask = (b >= 32 ? ~0u : ((1u << b) - 1u)) & ~((1u << a) - 1u);
+      m = (a == 0 ? enter : 0u) + (uint32_t)__popc(c.U & segmask) + (b == 32 ? cont : 0u);
+    }
+    MhlRec r;
+    r.first = row_off0 + (uint32_t)f;
+    r.last = r.first + (uint32_t)e - 1u;
+    r.m = m;
+    *out++ = r;
+    bits &= ~((e >= 32 ? ~0u : ((1u << e) - 1u)) << f);
+  }
+}
+
+__device__ __forceinline__ bool mhl_keep(uint32_t h, uint32_t oo_m, uint32_t oo_u, int32_t hmin, double max_oo) {
+  const double frac = (double)oo_m / (double)((uint64_t)oo_m + oo_u);      // :178 (0/0 = NaN -> kept)
+  return !((int)h < hmin || frac > max_oo);                                // :179
+}
+
+// Reads that fit one block of G x 32 bytes (every read of a short-read batch): 256/G reads per workgroup.
 template <int G>
-__global__ __launch_bounds__(256) void k_mhl_rows(const uint8_t *__restrict__ xm, const int64_t *__restrict__ off,
-                                                   int64_t n, uint32_t ctx_mask, int32_t hmin, double max_oo,
-                                                   uint16_t *__restrict__ m_out, int32_t *__restrict__ rowinfo) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
+  __shared__ uint32_t s_w[5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1);
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
-  const bool valid = row < n;
+  const bool valid = row < a.n;
   int64_t rs = 0, re = 0;
-  if (valid) { rs = off[row]; re = off[row + 1]; }
-  const int64_t c0 = rs >> 4;
-  const int64_t c1 = re > rs ? (re + 15) >> 4 : c0;
-  const int64_t nblk = (c1 - c0 + G - 1) / G;
+  if (valid) { rs = a.off[row]; re = a.off[row + 1]; }
+  const int64_t c0 = rs >> 5;
+  const int64_t c1 = re > rs ? (re + 31) >> 5 : c0;
+  const int64_t cidx = c0 + sub;
+  const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
 
-  if (nblk == 1) {
-    // ---- whole read inside one block of 16*G bytes: everything stays in registers ----
-    const int64_t c = c0 + sub;
-    const int64_t g0 = c << 4;
-    const bool live = c < c1;
-    uint4 w = make_uint4(0, 0, 0, 0);
-    if (live) w = *reinterpret_cast<const uint4 *>(xm + g0);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    uint32_t Ub = 0, Lb = 0, Mb = 0, Nb = 0, Vb = 0;       // per-byte bit masks: member, cut, ooctx meth/unmeth, in-row
+  // members of the open segment to the left (enter) and to the right (cont) of this lane
+  Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int64_t g = g0 + i;
-      const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
-      const uint32_t inrow = (live && g >= rs && g < re) ? 1u : 0u;
-      const uint32_t in = inrow & (ctx_mask >> code) & 1u;
-      Vb |= inrow << i;
-      Ub |= (in & (code < 8u ? 1u : 0u)) << i;
-      Lb |= (in & (code >= 8u ? 1u : 0u)) << i;
-      Mb |= (inrow & ~in & ((0x00E4u >> code) & 1u)) << i;   // codes 2,5,6,7   (:176)
-      Nb |= (inrow & ~in & ((0xE400u >> code) & 1u)) << i;   // codes 10,13,14,15 (:177)
-    }
-    uint32_t h = __popc(Ub | Lb), oo_m = __popc(Mb), oo_u = __popc(Nb);
-    // forward
-    uint32_t a0[16], b0[16];
-    Seg mf = {0u, 0u}, mb = {0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if ((Lb >> i) & 1u) { mf.has = 1u; mf.cnt = 0u; } else mf.cnt += (Ub >> i) & 1u;
-      a0[i] = mf.cnt;
-    }
-#pragma unroll
-    for (int i = 15; i >= 0; i--) {
-      if ((Lb >> i) & 1u) { mb.has = 1u; mb.cnt = 0u; } else mb.cnt += (Ub >> i) & 1u;
-      b0[i] = mb.cnt;
-    }
-    Seg incf = mf, incb = mb;
-#pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-      Seg l, r2;
-      l.has = __shfl_up(incf.has, d, G); l.cnt = __shfl_up(incf.cnt, d, G);
-      if (sub >= d) incf = seg_combine(l, incf);
-      r2.has = __shfl_down(incb.has, d, G); r2.cnt = __shfl_down(incb.cnt, d, G);
-      if (sub + d < G) incb = seg_combine(r2, incb);
-    }
-    Seg ef, eb;
-    ef.has = __shfl_up(incf.has, 1, G); ef.cnt = __shfl_up(incf.cnt, 1, G);
-    if (sub == 0) { ef.has = 0u; ef.cnt = 0u; }
-    eb.has = __shfl_down(incb.has, 1, G); eb.cnt = __shfl_down(incb.cnt, 1, G);
-    if (sub == G - 1) { eb.has = 0u; eb.cnt = 0u; }
-#pragma unroll
-    for (int d = G / 2; d >= 1; d >>= 1) {
-      h += __shfl_xor(h, d, 64);
-      oo_m += __shfl_xor(oo_m, d, 64);
-      oo_u += __shfl_xor(oo_u, d, 64);
-    }
-    bool keep = true;
-    {
-      const double frac = (double)oo_m / (double)((uint64_t)oo_m + oo_u);      // :178 (0/0 = NaN -> kept)
-      if ((int)h < hmin || frac > max_oo) keep = false;                        // :179
-    }
-    if (valid && sub == 0) rowinfo[row] = keep ? (int32_t)h : -1;
-    if (!keep || !live) return;
-    // bits at or after the first cut / at or before the last cut of this chunk
-    const uint32_t cut_f = Lb ? ~((Lb & (0u - Lb)) - 1u) : 0u;
-    const uint32_t cut_b = Lb ? ((2u << (31 - __clz(Lb))) - 1u) : 0u;
-    uint32_t mv[8];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      uint32_t av = a0[i], bv = b0[i];
-      if (!((cut_f >> i) & 1u)) av += ef.cnt;
-      if (!((cut_b >> i) & 1u)) bv += eb.cnt;
-      uint32_t m = 0;
-      if (!((Lb >> i) & 1u) && av > 0u && bv > 0u) { m = av + bv - ((Ub >> i) & 1u); if (m > 65535u) m = 65535u; }
-      if (i & 1) mv[i >> 1] |= m << 16; else mv[i >> 1] = m;
-    }
-    uint16_t *dst = m_out + g0;
-    if (Vb == 0xFFFFu) {                                  // whole chunk inside the read: two 16-byte stores
-      reinterpret_cast<uint4 *>(dst)[0] = make_uint4(mv[0], mv[1], mv[2], mv[3]);
-      reinterpret_cast<uint4 *>(dst)[1] = make_uint4(mv[4], mv[5], mv[6], mv[7]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        if ((Vb >> i) & 1u) dst[i] = (uint16_t)((mv[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-    }
-    return;
+  for (int d = 1; d < G; d <<= 1) {
+    Seg l, r;
+    l.has = __shfl_up(pf.has, d, G); l.cnt = __shfl_up(pf.cnt, d, G);
+    if (sub >= d) pf = seg_combine(l, pf);
+    r.has = __shfl_down(sf.has, d, G); r.cnt = __shfl_down(sf.cnt, d, G);
+    if (sub + d < G) sf = seg_combine(r, sf);                // walking leftwards: `r` was seen first
   }
-
-  uint32_t h = 0, oo_m = 0, oo_u = 0;
-  // ---- reads longer than one block: forward pass stores A(i) in m_out, backward pass turns it into m ----
-  Seg carry = {0u, 0u};
-  for (int64_t blk = 0; blk < nblk; blk++) {
-    const int64_t c = c0 + blk * G + sub;
-    const int64_t g0 = c << 4;
-    uint4 w = make_uint4(0, 0, 0, 0);
-    const bool live = c < c1;
-    if (live) w = *reinterpret_cast<const uint4 *>(xm + g0);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    uint32_t a0[16];
-    uint32_t cutseen = 0;      // bit i: a cut at index <= i inside this chunk
-    Seg me = {0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int64_t g = g0 + i;
-      const bool inrow = live && g >= rs && g < re;
-      const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
-      const bool in = inrow && ((ctx_mask >> code) & 1u);
-      const bool U = in && code < 8u, Lw = in && code >= 8u;
-      if (inrow) {
-        h += in;
-        if (!in) {
-          oo_m += (code == 2u) | (code == 5u) | (code == 6u) | (code == 7u);
-          oo_u += (code == 10u) | (code == 13u) | (code == 14u) | (code == 15u);
-        }
-      }
-      if (Lw) { me.has = 1u; me.cnt = 0u; } else me.cnt += U;
-      if (me.has) cutseen |= 1u << i;
-      a0[i] = Lw ? 0u : me.cnt;
-    }
-    // inclusive scan of chunk summaries over the group, then the state entering this chunk
-    Seg inc = me;
-#pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-      Seg l;
-      l.has = __shfl_up(inc.has, d, G);
-      l.cnt = __shfl_up(inc.cnt, d, G);
-      if (sub >= d) inc = seg_combine(l, inc);
-    }
-    Seg ex;
-    ex.has = __shfl_up(inc.has, 1, G);
-    ex.cnt = __shfl_up(inc.cnt, 1, G);
-    if (sub == 0) { ex.has = 0u; ex.cnt = 0u; }
-    const Seg entering = seg_combine(carry, ex);
-    Seg last;
-    last.has = __shfl(inc.has, G - 1, G);
-    last.cnt = __shfl(inc.cnt, G - 1, G);
-    carry = seg_combine(carry, last);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int64_t g = g0 + i;
-      if (live && g >= rs && g < re) {
-        uint32_t a = a0[i];
-        const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
-        const bool Lw = ((ctx_mask >> code) & 1u) && code >= 8u;
-        if (!Lw && !((cutseen >> i) & 1u)) a += entering.cnt;
-        m_out[g] = (uint16_t)(a > 65535u ? 65535u : a);
-      }
-    }
-  }
-  // row totals
+  uint32_t enter = __shfl_up(pf.cnt, 1, G), cont = __shfl_down(sf.cnt, 1, G);
+  if (sub == 0) enter = 0u;
+  if (sub == G - 1) cont = 0u;
+  uint32_t h = __popc(c.U | c.L), oo_m = c.oom, oo_u = c.oou, anyk = c.K ? 1u : 0u;
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) {
     h += __shfl_xor(h, d, 64);
     oo_m += __shfl_xor(oo_m, d, 64);
     oo_u += __shfl_xor(oo_u, d, 64);
+    anyk |= __shfl_xor(anyk, d, 64);
   }
-  bool keep = true;
-  {
-    const double frac = (double)oo_m / (double)((uint64_t)oo_m + oo_u);      // :178 (0/0 = NaN -> kept)
-    if ((int)h < hmin || frac > max_oo) keep = false;                        // :179
-  }
-  if (valid && sub == 0) rowinfo[row] = keep ? (int32_t)h : -1;
+  const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
+  const uint32_t P = keep ? span_bits(c, enter, cont) : 0u;
+  const uint32_t Q = (keep && anyk) ? (c.V & ~c.K) : 0u;
+  const uint32_t nrec = run_count(P) + run_count(Q);
 
-  // ---- backward: B(i), then m = A + B - member ----
-  carry.has = 0u; carry.cnt = 0u;
-  for (int64_t blk = nblk - 1; blk >= 0; blk--) {
-    const int64_t c = c0 + blk * G + sub;
-    const int64_t g0 = c << 4;
-    uint4 w = make_uint4(0, 0, 0, 0);
-    const bool live = c < c1;
-    if (live) w = *reinterpret_cast<const uint4 *>(xm + g0);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-    uint32_t b0[16];
-    uint32_t cutseen = 0;      // bit i: a cut at index >= i inside this chunk
-    Seg me = {0u, 0u};
+  // record slots: exclusive scan over the workgroup, one cursor atomic per workgroup
+  uint32_t inc = nrec;
 #pragma unroll
-    for (int i = 15; i >= 0; i--) {
-      const int64_t g = g0 + i;
-      const bool inrow = live && g >= rs && g < re;
-      const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
-      const bool in = inrow && ((ctx_mask >> code) & 1u);
-      const bool U = in && code < 8u, Lw = in && code >= 8u;
-      if (Lw) { me.has = 1u; me.cnt = 0u; } else me.cnt += U;
-      if (me.has) cutseen |= 1u << i;
-      b0[i] = Lw ? 0u : me.cnt;
-    }
-    // suffix scan: state entering this chunk from the right
-    Seg inc = me;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t t = s_w[w]; s_w[w] = acc; acc += t; }
+    const uint32_t region = blockIdx.x & (MHL_REGIONS - 1), region_cap = a.rec_cap / MHL_REGIONS;
+    unsigned long long base = 0;
+    if (acc) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)acc);
+    s_w[4] = (base + acc <= (unsigned long long)region_cap) ? region * region_cap + (uint32_t)base : 0xFFFFFFFFu;   // does not fit: count only
+  }
+  __syncthreads();
+  const uint32_t base = s_w[4];
+  const uint32_t my = base + s_w[wave] + inc - nrec;
+  uint32_t row_n = nrec;
 #pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
+  for (int d = G / 2; d >= 1; d >>= 1) row_n += __shfl_xor(row_n, d, 64);
+  if (valid && sub == 0) {
+    a.rowinfo[2 * row] = keep ? (int32_t)h : -1;
+    a.rowinfo[2 * row + 1] = (int32_t)anyk;
+    a.blkrec[row] = make_uint2(my, base == 0xFFFFFFFFu ? 0u : row_n);
+  }
+  if (nrec && base != 0xFFFFFFFFu) {
+    const uint32_t off0 = (uint32_t)((cidx << 5) - rs);      // row offset of the chunk's byte 0 (wraps for the first chunk)
+    MhlRec *out = a.recs + my;
+    write_runs(P, true, c, enter, cont, off0, out);
+    write_runs(Q, false, c, enter, cont, off0, out + run_count(P));
+  }
+}
+
+// Any read length: one wavefront per read, blocks of 64 x 32 bytes.  A backward sweep leaves, per block, the members
+// that enter it from the right (and the read's totals); the forward sweep then has both sides and writes the records
+// of each block (pass 2 looks records up by block, so a long read is never scanned whole).
+__global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n) return;
+  const int64_t rs = a.off[row], re = a.off[row + 1];
+  const int64_t c0 = rs >> 5;
+  const int64_t c1 = re > rs ? (re + 31) >> 5 : c0;
+  const int64_t nblk = (c1 - c0 + 63) >> 6;
+  const int64_t bi = (rs >> MHL_BLK_SHIFT) + 2 * row;        // this read's slots in blkrec / cont (>= nblk of them)
+  uint32_t h = 0, oo_m = 0, oo_u = 0, anyk = 0;
+  uint32_t from_right = 0;
+  for (int64_t b = nblk - 1; b >= 0; b--) {
+    const int64_t cidx = c0 + b * 64 + lane;
+    const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    h += __popc(c.U | c.L); oo_m += c.oom; oo_u += c.oou; anyk |= c.K ? 1u : 0u;
+    Seg sf = {c.L ? 1u : 0u, lead_members(c)};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
       Seg r;
-      r.has = __shfl_down(inc.has, d, G);
-      r.cnt = __shfl_down(inc.cnt, d, G);
-      if (sub + d < G) inc = seg_combine(r, inc);      // walking leftwards: `r` was seen first
+      r.has = __shfl_down(sf.has, d, 64); r.cnt = __shfl_down(sf.cnt, d, 64);
+      if (lane + d < 64) sf = seg_combine(r, sf);
     }
-    Seg ex;
-    ex.has = __shfl_down(inc.has, 1, G);
-    ex.cnt = __shfl_down(inc.cnt, 1, G);
-    if (sub == G - 1) { ex.has = 0u; ex.cnt = 0u; }
-    const Seg entering = seg_combine(carry, ex);
-    Seg first;
-    first.has = __shfl(inc.has, 0, G);
-    first.cnt = __shfl(inc.cnt, 0, G);
-    carry = seg_combine(carry, first);
+    if (lane == 0) __atomic_store_n(a.cont + bi + b, from_right, __ATOMIC_RELAXED);
+    const uint32_t bh = __shfl(sf.has, 0, 64), bc = __shfl(sf.cnt, 0, 64);
+    from_right = bh ? bc : bc + from_right;
+  }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int64_t g = g0 + i;
-      if (live && g >= rs && g < re) {
-        const uint32_t code = (ww[i >> 2] >> (8 * (i & 3))) & 15u;
-        const bool in = (ctx_mask >> code) & 1u;
-        const bool U = in && code < 8u, Lw = in && code >= 8u;
-        uint32_t bv = b0[i];
-        if (!Lw && !((cutseen >> i) & 1u)) bv += entering.cnt;
-        const uint32_t av = m_out[g];
-        uint32_t m = 0;
-        if (!Lw && av > 0u && bv > 0u) { m = av + bv - (U ? 1u : 0u); if (m > 65535u) m = 65535u; }
-        m_out[g] = keep ? (uint16_t)m : (uint16_t)0;
-      }
+  for (int d = 32; d >= 1; d >>= 1) {
+    h += __shfl_xor(h, d, 64);
+    oo_m += __shfl_xor(oo_m, d, 64);
+    oo_u += __shfl_xor(oo_u, d, 64);
+    anyk |= __shfl_xor(anyk, d, 64);
+  }
+  const bool keep = mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
+  if (lane == 0) {
+    a.rowinfo[2 * row] = keep ? (int32_t)h : -1;
+    a.rowinfo[2 * row + 1] = (int32_t)anyk;
+  }
+  if (!keep) return;
+  __threadfence();
+  Seg carry = {0u, 0u};
+  for (int64_t b = 0; b < nblk; b++) {
+    const int64_t cidx = c0 + b * 64 + lane;
+    const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      Seg l, r;
+      l.has = __shfl_up(pf.has, d, 64); l.cnt = __shfl_up(pf.cnt, d, 64);
+      if (lane >= d) pf = seg_combine(l, pf);
+      r.has = __shfl_down(sf.has, d, 64); r.cnt = __shfl_down(sf.cnt, d, 64);
+      if (lane + d < 64) sf = seg_combine(r, sf);
+    }
+    Seg ex, exr;
+    ex.has = __shfl_up(pf.has, 1, 64); ex.cnt = __shfl_up(pf.cnt, 1, 64);
+    if (lane == 0) { ex.has = 0u; ex.cnt = 0u; }
+    exr.has = __shfl_down(sf.has, 1, 64); exr.cnt = __shfl_down(sf.cnt, 1, 64);
+    if (lane == 63) { exr.has = 0u; exr.cnt = 0u; }
+    const uint32_t enter = seg_combine(carry, ex).cnt;
+    Seg last;
+    last.has = __shfl(pf.has, 63, 64); last.cnt = __shfl(pf.cnt, 63, 64);
+    carry = seg_combine(carry, last);
+    const uint32_t right = __atomic_load_n(a.cont + bi + b, __ATOMIC_RELAXED);
+    const uint32_t cont = exr.has ? exr.cnt : exr.cnt + right;
+    const uint32_t P = span_bits(c, enter, cont);
+    const uint32_t Q = anyk ? (c.V & ~c.K) : 0u;
+    const uint32_t nrec = run_count(P) + run_count(Q);
+    uint32_t inc = nrec;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    const uint32_t total = __shfl(inc, 63, 64);
+    const uint32_t region = blockIdx.x & (MHL_REGIONS - 1), region_cap = a.rec_cap / MHL_REGIONS;
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)total);
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+    const bool fits = base + total <= (unsigned long long)region_cap;
+    base += (unsigned long long)region * region_cap;
+    if (lane == 0) a.blkrec[bi + b] = make_uint2((uint32_t)base, fits ? total : 0u);
+    if (nrec && fits) {
+      const uint32_t off0 = (uint32_t)((cidx << 5) - rs);
+      MhlRec *out = a.recs + (uint32_t)base + inc - nrec;
+      write_runs(P, true, c, enter, cont, off0, out);
+      write_runs(Q, false, c, enter, cont, off0, out + run_count(P));
     }
   }
 }
 
+// largest region usage -> *out (the host compares it with the region capacity)
+__global__ void k_mhl_cursor_max(const unsigned long long *cur, unsigned long long *out) {
+  unsigned long long v = cur[threadIdx.x * MHL_CUR_STRIDE];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(v >> 32), d, 64) << 32) | __shfl_xor((uint32_t)v, d, 64);
+    v = o > v ? o : v;
+  }
+  if (threadIdx.x == 0) *out = v;
+}
+
 struct MhlArgs {
   RowCols c;                              // pass is always null here (no lower-casing in lMHL)
-  const uint16_t *m;
   const int32_t *rowinfo;
+  const uint2 *blkrec;
+  const MhlRec *recs;
+  uint32_t rec_cap;
+  int multi;                              // records are kept per 2 KiB block of a row (k_mhl_rows_multi)
+  int ablate;                             // timing experiments only (EPIHIP_MHL_ABLATE)
   const Tile *tiles;
   uint32_t ctx_mask, H;
   uint32_t *pool_key, *pool_cov;
@@ -291,70 +382,85 @@ struct MhlArgs {
   int heavy_rows, heavy_chunk;
   uint32_t *heavy_count, *heavy_max, *heavy_list;
   uint32_t *heavy_cnt;                    // [heavy tile][16][T] counters
-  unsigned long long *heavy_sums;         // [heavy tile][2T + 4(T+1)] numerator sums and difference arrays
+  unsigned long long *heavy_sums;         // [heavy tile][MHL_NSUM] difference arrays
   // tiles shared with other ranks of a sharded run: same two slabs, indexed by shared slot
   uint32_t *shared_cnt;
   unsigned long long *shared_sums;
 };
 
-constexpr int MHL_T = kMhlTile;
-constexpr int MHL_NSUM = 2 * kMhlTile + 4 * (kMhlTile + 1);
-
-// nibble -> flags of the rarely taken per-byte path: 1 = '+'/'-' (skipped, :187), 2/4/8 = stray nibbles
-// 3/4/8, whose counter slot IS the numerator / denominator / haplotype-size sum in the reference (:190)
+// nibble -> flags of the rarely taken per-byte path: stray nibbles 3 / 4 / 8, whose counter slot IS the numerator /
+// denominator / haplotype-size sum in the reference (:190)
 //   code:  0 1 2 3 4 5 6 7 | 8 9 10 11 | 12..15
-//   flag:  0 0 0 2 4 0 0 0 | 8 0  0  1 |  0
-constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x01000008u, kFlagHi1 = 0x00000000u;
+//   flag:  0 0 0 2 4 0 0 0 | 8 0  0  0 |  0
+constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x00000008u, kFlagHi1 = 0x00000000u;
+
+struct MhlLds {
+  uint32_t *cnt;                          // [2][4][T] packed code counters (as the CX kernel)
+  unsigned long long *sums;               // [3][2][T+1] difference arrays of sum S(M) (:193), sum h (:192), sum S(h) (:194)
+};
+constexpr int MHL_DN = 0, MHL_DH = 2 * (MHL_T + 1), MHL_DD = 4 * (MHL_T + 1);
 
 struct MhlSlice {
   RowSlice rs;
-  const uint2 *msrc;                      // this lane's first four stretch sizes (u16 each), parallel to rs.src
   int pos0;                               // tile position of byte 0 of this lane's first dword (may be -1..-3)
   int pf, pe;                             // tile positions [pf, pe) the slice covers
   int sidx;                               // 0 '+', 1 '-'
-  uint32_t h;                             // haplotype size of the row
+  uint32_t hs;                            // haplotype size of the read | bit 31: the read has skipped bytes (its counted
+                                          // runs come as records)
+  int32_t rel;                            // tile position of the read's byte 0 = start - pos0
+  int32_t blk0, blk1;                     // record blocks of the read that can reach into the tile
 };
 
-template <int G>
-__device__ __forceinline__ MhlSlice mhl_row_slice(const MhlArgs &a, const Tile &td, int r, int sub, uint32_t *cnt) {
-  MhlSlice m;
-  m.rs = cx_row_slice<MHL_T, G>(a.c, td, r, sub, cnt);
-  m.msrc = nullptr; m.pos0 = 0; m.pf = 0; m.pe = 0; m.sidx = 0; m.h = 0;
-  if (m.rs.nd > 0) {
-    const int32_t hrow = a.rowinfo[r];
-    if (hrow < 0) { m.rs.nd = 0; return m; }            // read skipped by pass 1 (:179)
-    m.h = (uint32_t)hrow;
-    const int32_t st = a.c.start[r];
-    const int64_t o = a.c.off[r];
-    const int32_t len = (int32_t)((uint32_t)a.c.off[r + 1] - (uint32_t)o);
-    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)st);
-    const int32_t lo = rel > 0 ? rel : 0;
-    const int32_t hi = len < rel + MHL_T ? len : rel + MHL_T;
-    const int64_t b0 = o + lo;
-    const int32_t e_lo = (int32_t)b0 & 3;
-    m.msrc = reinterpret_cast<const uint2 *>(a.m + (b0 - e_lo)) + sub;
-    m.pf = lo - rel;
-    m.pe = hi - rel;
-    m.pos0 = m.pf - e_lo + 4 * sub;
-    m.sidx = a.c.strand[r] - 1;
+struct MhlRow {                           // what a lane prefetches of a candidate row
+  RowVals v;
+  int32_t hrow, skips;
+};
+
+__device__ __forceinline__ MhlRow mhl_load_row(const MhlArgs &a, const Tile &td, int r) {
+  MhlRow m;
+  m.v = cx_load_row(a.c, td, r);
+  m.hrow = -1; m.skips = 0;
+  if (m.v.ok) {
+    const int2 ri = reinterpret_cast<const int2 *>(a.rowinfo)[r];
+    m.hrow = ri.x; m.skips = ri.y;
+    if (m.hrow < 0) m.v.ok = false;                       // read dropped by pass 1 (:179)
   }
   return m;
 }
 
-struct MhlLds {
-  uint32_t *cnt;                          // [2][8][T] code counters (as the CX kernel)
-  unsigned long long *num;                // [2][T]    sum of S(m_i)                       (:193)
-  unsigned long long *dh, *dd;            // [2][T+1]  difference arrays of sum(h) (:192) and sum(S(h)) (:194)
-};
+template <int G>
+__device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow &row, const Tile &td, int sub, uint32_t *cnt) {
+  MhlSlice m;
+  m.rs = cx_slice_of<MHL_T, G, true>(a.c, row.v, td, sub, cnt);
+  m.pos0 = 0; m.pf = 0; m.pe = 0; m.sidx = 0; m.hs = 0; m.rel = 0; m.blk0 = 0; m.blk1 = -1;
+  if (m.rs.nd > 0) {
+    m.hs = (uint32_t)row.hrow | (row.skips ? 0x80000000u : 0u);
+    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)row.v.st);
+    const int32_t lo = rel > 0 ? rel : 0;
+    const int32_t hi = row.v.len < rel + MHL_T ? row.v.len : rel + MHL_T;
+    const int64_t b0 = row.v.o + lo;
+    const int32_t e_lo = (int32_t)b0 & 3;
+    m.pf = lo - rel;
+    m.pe = hi - rel;
+    m.pos0 = m.pf - e_lo + 4 * sub;
+    m.sidx = row.v.sd - 1;
+    m.rel = -rel;
+    if (a.multi) {
+      const int64_t c0 = row.v.o >> 5;
+      m.blk0 = (int32_t)((((row.v.o + lo) >> 5) - c0) >> 6);
+      m.blk1 = (int32_t)((((row.v.o + hi - 1) >> 5) - c0) >> 6);
+    } else {
+      m.blk0 = 0; m.blk1 = 0;
+    }
+  }
+  return m;
+}
 
-// One dword of a row: the CX counters, plus -- only where a byte needs it -- the numerator sum, the
-// corrections for skipped bytes and the stray-nibble increments.  sum(h) and sum(S(h)) are the same for
-// every counted byte of a row, so they are added as an interval (+v at the slice start, -v after its end,
-// prefix-summed at emit time) instead of one 64-bit atomic per byte.
+// One dword of a row: the packed CX counters; stray nibbles 3/4/8 additionally bump one of the three sums at their
+// position (+1 there, -1 after it, in the difference arrays).
 template <int OFF, bool FIRST>
-__device__ __forceinline__ void mhl_add_dword(uint32_t w, uint2 mm, int k, const MhlSlice &m, const MhlLds &L,
-                                              uint32_t H, unsigned long long sh) {
-  cx_add_dword<MHL_T, OFF, FIRST>(w, k, m.rs);
+__device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice &m, const MhlLds &L) {
+  cx_add_dword<MHL_T, OFF, FIRST, true>(w, k, m.rs);
   const uint32_t c4 = w & 0x0F0F0F0Fu;
   const uint32_t lo3 = c4 & 0x07070707u;
   const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
@@ -362,25 +468,31 @@ __device__ __forceinline__ void mhl_add_dword(uint32_t w, uint2 mm, int k, const
   if (FIRST) vm &= m.rs.mask_first;
   const uint32_t f4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(kFlagHi1, kFlagHi0, lo3),
                                             __builtin_amdgcn_perm(kFlagLo1, kFlagLo0, lo3), pick) & vm;
-  if ((f4 | mm.x | mm.y) == 0u) return;                  // common case: nothing but the counters
+  if (f4 == 0u) return;                                  // common case: nothing but the counters
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    if (!((vm >> (8 * j)) & 1u)) continue;               // byte outside the slice (its m may be anything)
     const uint32_t fl = (f4 >> (8 * j)) & 0xFFu;
-    const uint32_t mi = ((j & 2) ? mm.y : mm.x) >> (16 * (j & 1)) & 0xFFFFu;
-    const int p = m.pos0 + OFF + j;
-    unsigned long long *dh = L.dh + m.sidx * (MHL_T + 1) + p;
-    unsigned long long *dd = L.dd + m.sidx * (MHL_T + 1) + p;
-    if (fl & 1u) {                                       // '+'/'-': not counted, take the row's interval add back
-      atomicAdd(dh, 0ull - (unsigned long long)m.h); atomicAdd(dh + 1, (unsigned long long)m.h);
-      atomicAdd(dd, 0ull - sh); atomicAdd(dd + 1, sh);
-    } else {
-      const unsigned long long ni = (mi ? mhl_lut(mi, H) : 0ull) + ((fl & 2u) ? 1ull : 0ull);
-      if (ni) atomicAdd(L.num + m.sidx * MHL_T + p, ni);
-      if (fl & 4u) { atomicAdd(dd, 1ull); atomicAdd(dd + 1, 0ull - 1ull); }
-      if (fl & 8u) { atomicAdd(dh, 1ull); atomicAdd(dh + 1, 0ull - 1ull); }
-    }
+    if (!fl) continue;
+    const int p = m.sidx * (MHL_T + 1) + m.pos0 + OFF + j;
+    unsigned long long *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + p;
+    atomicAdd(d, 1ull);
+    atomicAdd(d + 1, 0ull - 1ull);
   }
+}
+
+template <int G, int U0, int U1>
+__device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int sub, const MhlSlice &cur, const MhlLds &L) {
+  if constexpr (U0 < U1) {
+    if (sub + U0 * G < cur.rs.nd) mhl_add_dword<4 * G * U0, U0 == 0>(w[U0], sub + U0 * G, cur, L);
+    mhl_add_range<G, U0 + 1, U1>(w, sub, cur, L);
+  }
+}
+
+// +v on tile positions [a, b) of one difference array
+__device__ __forceinline__ void mhl_interval(unsigned long long *d, int64_t a, int64_t b, unsigned long long v) {
+  if (a < 0) a = 0;
+  if (b > MHL_T) b = MHL_T;
+  if (a < b) { atomicAdd(d + a, v); atomicAdd(d + b, 0ull - v); }
 }
 
 template <int G, int WG>
@@ -390,80 +502,104 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   int r = td.row_lo + wave * R + grp;
-  MhlSlice cur = mhl_row_slice<G>(a, td, r, sub, L.cnt);
+  MhlRow row = mhl_load_row(a, td, r);
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
-    uint32_t w[CX_UN];
-    uint2 mm[CX_UN];
+    const MhlSlice cur = mhl_slice_of<G>(a, row, td, sub, L.cnt);
+    uint32_t w[CX_NU];
 #pragma unroll
-    for (int u = 0; u < CX_UN; u++) {
-      const bool on = sub + u * G < cur.rs.nd;
-      w[u] = on ? cur.rs.src[u * G] : 0u;
-      mm[u] = on ? cur.msrc[u * G] : make_uint2(0u, 0u);
-    }
+    for (int u = 0; u < CX_NU; u++) w[u] = sub + u * G < cur.rs.nd ? cur.rs.src[u * G] : 0u;
+    const int rcur = r;
+    const int64_t ocur = row.v.o;
     r += NW * R;
-    const MhlSlice nxt = mhl_row_slice<G>(a, td, r, sub, L.cnt);
-    const unsigned long long sh = mhl_lut(cur.h, a.H);   // S(h), :194
-    if (cur.rs.nd > 0 && sub == 0) {                     // the row's interval adds
-      unsigned long long *dh = L.dh + cur.sidx * (MHL_T + 1);
-      unsigned long long *dd = L.dd + cur.sidx * (MHL_T + 1);
-      atomicAdd(dh + cur.pf, (unsigned long long)cur.h); atomicAdd(dh + cur.pe, 0ull - (unsigned long long)cur.h);
-      atomicAdd(dd + cur.pf, sh); atomicAdd(dd + cur.pe, 0ull - sh);
+    row = mhl_load_row(a, td, r);                          // the next step's columns are in flight during this step's adds
+    if (cur.rs.nd > 0) {
+      const uint32_t h = cur.hs & 0x7FFFFFFFu;
+      const unsigned long long sh = mhl_lut(h, a.H);       // S(h), :194
+      unsigned long long *dn = L.sums + MHL_DN + cur.sidx * (MHL_T + 1);
+      unsigned long long *dh = L.sums + MHL_DH + cur.sidx * (MHL_T + 1);
+      unsigned long long *dd = L.sums + MHL_DD + cur.sidx * (MHL_T + 1);
+      if (!(cur.hs >> 31) && sub == 0 && !(a.ablate & 4)) {   // every byte of the slice is counted: one interval per sum
+        mhl_interval(dh, cur.pf, cur.pe, (unsigned long long)h);
+        mhl_interval(dd, cur.pf, cur.pe, sh);
+      }
+      const int64_t bi = a.multi ? (ocur >> MHL_BLK_SHIFT) + 2 * (int64_t)rcur : (int64_t)rcur;
+      for (int32_t blk = cur.blk0; blk <= ((a.ablate & 2) ? -1 : cur.blk1); blk++) {   // the stretch pieces (and counted runs) near the tile
+        const uint2 br = a.blkrec[bi + blk];
+        if ((uint64_t)br.x + br.y > a.rec_cap) continue;       // pass 1 ran out of record space: the caller reruns
+        for (uint32_t k = (uint32_t)sub; k < br.y; k += G) {
+          const MhlRec rec = a.recs[br.x + k];
+          const int64_t ta = (int64_t)cur.rel + rec.first, tb = (int64_t)cur.rel + rec.last + 1;
+          if (rec.m) mhl_interval(dn, ta, tb, mhl_lut(rec.m, a.H));
+          else { mhl_interval(dh, ta, tb, (unsigned long long)h); mhl_interval(dd, ta, tb, sh); }
+        }
+      }
     }
-    if (sub < cur.rs.nd) mhl_add_dword<0, true>(w[0], mm[0], sub, cur, L, a.H, sh);
-    if (sub + G < cur.rs.nd) mhl_add_dword<4 * G, false>(w[1], mm[1], sub + G, cur, L, a.H, sh);
-    if (sub + 2 * G < cur.rs.nd) mhl_add_dword<8 * G, false>(w[2], mm[2], sub + 2 * G, cur, L, a.H, sh);
-    if (sub + 3 * G < cur.rs.nd) mhl_add_dword<12 * G, false>(w[3], mm[3], sub + 3 * G, cur, L, a.H, sh);
-    if (sub + 4 * G < cur.rs.nd) mhl_add_dword<16 * G, false>(w[4], mm[4], sub + 4 * G, cur, L, a.H, sh);
-    for (int k = sub + CX_UN * G; k < cur.rs.nd; k += G) {
+    if (!(a.ablate & 8)) mhl_add_range<G, 0, CX_NU>(w, sub, cur, L);
+    for (int k = sub + CX_NU * G; k < cur.rs.nd; k += G) {
       MhlSlice t = cur;
 #pragma unroll
       for (int j = 0; j < 4; j++) t.rs.dst[j] = cur.rs.dst[j] + 4 * (k - sub);
       t.pos0 = cur.pos0 + 4 * (k - sub);
-      mhl_add_dword<0, false>(cur.rs.src[k - sub], cur.msrc[k - sub], k, t, L, a.H, sh);
+      mhl_add_dword<0, false>(cur.rs.src[k - sub], k, t, L);
     }
-    cur = nxt;
   }
 }
 
-// inclusive prefix sum of one u64 per thread over the workgroup (NW wavefronts)
-template <int NW>
-__device__ __forceinline__ unsigned long long block_incl_scan_u64(unsigned long long v, unsigned long long *s_w) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t lo = __shfl_up((uint32_t)v, d, 64);
-    const uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, 64);
-    if (lane >= d) v += ((unsigned long long)hi << 32) | lo;
-  }
-  if (lane == 63) s_w[wave] = v;
-  __syncthreads();
-  unsigned long long add = 0;
-  for (int w = 0; w < wave; w++) add += s_w[w];
-  __syncthreads();
-  return v + add;
-}
-
-// Rule, prefix sums of the interval arrays, ordered compaction of one tile (one position per thread).
-template <int WG>
-__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, unsigned long long *s_w,
+// Rule, prefix sums of the difference arrays, ordered compaction of one tile (one position per thread).
+template <int WG, bool PK>
+__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, unsigned long long *s_w /* [6][NW] */,
                                          uint32_t *s_scan) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
+  static_assert(WG == T, "one position per thread in the emit phase");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // emit: one position per thread, '+' then '-'
   const int p = threadIdx.x;
-  const bool live = p < T;
+  // six block-wide inclusive scans at once: wave scans, one exchange of the wave totals
+  unsigned long long v[6];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    v[3 * s + 0] = L.sums[MHL_DH + s * (T + 1) + p];
+    v[3 * s + 1] = L.sums[MHL_DD + s * (T + 1) + p];
+    v[3 * s + 2] = L.sums[MHL_DN + s * (T + 1) + p];
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const uint32_t lo = __shfl_up((uint32_t)v[i], d, 64);
+      const uint32_t hi = __shfl_up((uint32_t)(v[i] >> 32), d, 64);
+      if (lane >= d) v[i] += ((unsigned long long)hi << 32) | lo;
+    }
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) s_w[i * NW + wave] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    unsigned long long add = 0;
+    for (int w = 0; w < wave; w++) add += s_w[i * NW + w];
+    v[i] += add;
+  }
   uint32_t key[2], cov[2];
   double len[2], lm[2];
   bool ok[2];
   int nr = 0;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    const unsigned long long hs = block_incl_scan_u64<NW>(live ? L.dh[s * (T + 1) + p] : 0ull, s_w);   // :192
-    const unsigned long long de = block_incl_scan_u64<NW>(live ? L.dd[s * (T + 1) + p] : 0ull, s_w);   // :194
     uint32_t c[8];
+    if constexpr (PK) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = live ? L.cnt[(s * 8 + k) * T + p] : 0u;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w = L.cnt[(s * 4 + k) * T + p];
+        c[2 * k] = w & 0xFFFFu;
+        c[2 * k + 1] = w >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = L.cnt[(s * 8 + k) * T + p];
+    }
     const uint32_t nH = c[SLOT_H] + c[SLOT_h], nX = c[SLOT_X] + c[SLOT_x], nZ = c[SLOT_Z] + c[SLOT_z];
     const uint32_t cv = c[SLOT_DOT] + c[SLOT_OTHER] + nH + nX + nZ;
     const uint32_t half = cv >> 1;                                           // :77
@@ -478,9 +614,8 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     ok[s] = k != 0;
     key[s] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
     cov[s] = cc;                                                             // :90
-    const unsigned long long nu = live ? L.num[s * T + p] : 0ull;
-    len[s] = (double)hs / (double)(int)cc;                                   // :92
-    lm[s] = (double)nu / (double)de;                                         // :93
+    len[s] = (double)v[3 * s + 0] / (double)(int)cc;                         // :92
+    lm[s] = (double)v[3 * s + 2] / (double)v[3 * s + 1];                     // :93
     nr += k != 0;
   }
   uint32_t inc = (uint32_t)nr;
@@ -518,20 +653,25 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
   }
 }
 
+constexpr int MHL_LDS_CNT = cx_lds_dwords<MHL_T, true>() + 2 * kCxGuard;
+
+__device__ __forceinline__ MhlLds mhl_lds(uint32_t *cnt, unsigned long long *sums) {
+  MhlLds L;
+  L.cnt = cnt;
+  L.sums = sums;
+  return L;
+}
+
+// three workgroups per CU (41 KiB of LDS each): 6 waves per SIMD
 template <int G, int WG>
-__global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
+__global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
-  static_assert(WG >= T, "one position per thread in the emit phase");
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
   __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  __shared__ unsigned long long s_w[NW];
+  __shared__ unsigned long long s_w[6 * NW];
   __shared__ uint32_t s_scan[NW + 2];
-  MhlLds L;
-  L.cnt = cnt_raw + kCxGuard;
-  L.num = sums;
-  L.dh = sums + 2 * T;
-  L.dd = sums + 2 * T + 2 * (T + 1);
+  const MhlLds L = mhl_lds(cnt_raw + kCxGuard, sums);
   const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
@@ -546,97 +686,76 @@ __global__ __launch_bounds__(WG) void k_mhl_tiles(MhlArgs a, int ntiles) {
     }
     return;
   }
-  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
+  for (int i = threadIdx.x; i < MHL_LDS_CNT; i += WG) cnt_raw[i] = 0;
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
   if (td.slot >= 0) {                                    // shared with another rank: hand the raw sums over
-    uint32_t *dc = a.shared_cnt + (int64_t)td.slot * (16 * T);
+    cx_dump_slab<T, WG, true>(L.cnt, reinterpret_cast<int32_t *>(a.shared_cnt + (int64_t)td.slot * (16 * T)));
     unsigned long long *ds = a.shared_sums + (int64_t)td.slot * MHL_NSUM;
-    for (int i = threadIdx.x; i < 16 * T; i += WG) { const uint32_t v = L.cnt[i]; if (v) atomicAdd(dc + i, v); }
     for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
-  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+  if (a.ablate & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
+  mhl_emit<WG, true>(a, tile, L, s_w, s_scan);
 }
 
 // One chunk of the candidate rows of one heavy tile -> added into that tile's slab in HBM.
 template <int G, int WG>
-__global__ __launch_bounds__(WG) void k_mhl_heavy(MhlArgs a) {
+__global__ __launch_bounds__(WG, 6) void k_mhl_heavy(MhlArgs a) {
   constexpr int T = MHL_T;
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[16 * T + 2 * kCxGuard];
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
   __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  MhlLds L;
-  L.cnt = cnt_raw + kCxGuard;
-  L.num = sums;
-  L.dh = sums + 2 * T;
-  L.dd = sums + 2 * T + 2 * (T + 1);
+  const MhlLds L = mhl_lds(cnt_raw + kCxGuard, sums);
   const int tile = (int)a.heavy_list[blockIdx.y];
   Tile td = a.tiles[tile];
   const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
   if (lo >= td.row_hi) return;
   td.row_lo = lo;
   if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
-  for (int i = threadIdx.x; i < 16 * T + 2 * kCxGuard; i += WG) cnt_raw[i] = 0;
+  for (int i = threadIdx.x; i < MHL_LDS_CNT; i += WG) cnt_raw[i] = 0;
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
   uint32_t *dc = td.slot >= 0 ? a.shared_cnt + (int64_t)td.slot * (16 * T) : a.heavy_cnt + (int64_t)blockIdx.y * (16 * T);
   unsigned long long *ds = td.slot >= 0 ? a.shared_sums + (int64_t)td.slot * MHL_NSUM : a.heavy_sums + (int64_t)blockIdx.y * MHL_NSUM;
-  for (int i = threadIdx.x; i < 16 * T; i += WG) { const uint32_t v = L.cnt[i]; if (v) atomicAdd(dc + i, v); }
+  cx_dump_slab<T, WG, true>(L.cnt, reinterpret_cast<int32_t *>(dc));
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
 }
 
+// Rule + rows of one tile whose sums sit in HBM slabs (u32 counters [16][T] + MHL_NSUM u64): heavy and shared tiles.
 template <int WG>
-__global__ __launch_bounds__(WG) void k_mhl_emit_heavy(MhlArgs a) {
+__device__ __forceinline__ void mhl_emit_from_slab(const MhlArgs &a, int tile, const uint32_t *sc, const unsigned long long *ss) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
   __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  __shared__ unsigned long long s_w[NW];
+  __shared__ unsigned long long s_w[6 * NW];
   __shared__ uint32_t s_scan[NW + 2];
-  MhlLds L;
-  L.cnt = cnt;
-  L.num = sums;
-  L.dh = sums + 2 * T;
-  L.dd = sums + 2 * T + 2 * (T + 1);
-  const int tile = (int)a.heavy_list[blockIdx.x];
-  if (a.tiles[tile].slot >= 0) return;                   // emitted after the cross-rank reduce
-  const uint32_t *sc = a.heavy_cnt + (int64_t)blockIdx.x * (16 * T);
-  const unsigned long long *ss = a.heavy_sums + (int64_t)blockIdx.x * MHL_NSUM;
   for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
   __syncthreads();
-  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+  mhl_emit<WG, false>(a, tile, mhl_lds(cnt, sums), s_w, s_scan);
+}
+
+template <int WG>
+__global__ __launch_bounds__(WG) void k_mhl_emit_heavy(MhlArgs a) {
+  const int tile = (int)a.heavy_list[blockIdx.x];
+  if (a.tiles[tile].slot >= 0) return;                   // emitted after the cross-rank reduce
+  mhl_emit_from_slab<WG>(a, tile, a.heavy_cnt + (int64_t)blockIdx.x * (16 * MHL_T), a.heavy_sums + (int64_t)blockIdx.x * MHL_NSUM);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slabs: one workgroup per slot.
 template <int WG>
 __global__ __launch_bounds__(WG) void k_mhl_emit_slab(MhlArgs a, const int32_t *__restrict__ owned,
                                                        const int32_t *__restrict__ slot_tile) {
-  constexpr int T = MHL_T;
-  constexpr int NW = WG / 64;
-  __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
-  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  __shared__ unsigned long long s_w[NW];
-  __shared__ uint32_t s_scan[NW + 2];
   if (!owned[blockIdx.x]) return;
   const int tile = slot_tile[blockIdx.x];
   if (tile < 0) return;
-  MhlLds L;
-  L.cnt = cnt;
-  L.num = sums;
-  L.dh = sums + 2 * T;
-  L.dd = sums + 2 * T + 2 * (T + 1);
-  const uint32_t *sc = a.shared_cnt + (int64_t)blockIdx.x * (16 * T);
-  const unsigned long long *ss = a.shared_sums + (int64_t)blockIdx.x * MHL_NSUM;
-  for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
-  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
-  __syncthreads();
-  mhl_emit<WG>(a, tile, L, s_w, s_scan);
+  mhl_emit_from_slab<WG>(a, tile, a.shared_cnt + (int64_t)blockIdx.x * (16 * MHL_T), a.shared_sums + (int64_t)blockIdx.x * MHL_NSUM);
 }
 
 // one wavefront per tile: pool rows -> their place in the final table (see k_cx_gather)
@@ -713,17 +832,36 @@ static int pick_mhl_tile_group(int32_t max_len) {
   const int slice = (max_len < MHL_T ? max_len : MHL_T) + 3;
   const int nd = (slice + 3) / 4;
   int g = 8;
-  while (g < 64 && g * CX_UN < nd) g <<= 1;
+  while (g < 64 && g * CX_NU < nd) g <<= 1;
   return g;
 }
 
+// lanes per read in k_mhl_rows (32 bytes per lane, the read may start anywhere inside its first chunk); 0 = the batch
+// has reads longer than 64 lanes cover (or EPIHIP_MHL_MULTI is set): k_mhl_rows_multi
 static int pick_mhl_group(int32_t max_len) {
-  const char *env = getenv("EPIHIP_MHL_GROUP");
-  if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
-  const int64_t chunks = max_len / 16 + 2;      // so that most reads are a single block
-  int g = 1;
-  while (g < chunks && g < 64) g <<= 1;
+  if (getenv("EPIHIP_MHL_MULTI")) return 0;
+  const int64_t chunks = ((int64_t)max_len + 31 + 31) / 32;
+  if (chunks > 64) return 0;
+  int g = 2;
+  while (g < chunks) g <<= 1;
   return g;
+}
+
+// nibble -> MhlLut flags for one context set (rcpp_mhl_report.cpp:104-107, :176-177, :187)
+static MhlLut make_mhl_lut(uint32_t ctx_mask) {
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (uint32_t code = 0; code < 16; code++) {
+    const bool in = (ctx_mask >> code) & 1u;
+    uint32_t f = 0;
+    if (in) f |= code < 8 ? 1u : 2u;
+    if (code == 11) f |= 4u;
+    if (!in && ((0x00E4u >> code) & 1u)) f |= 8u;            // codes 2,5,6,7
+    if (!in && ((0xE400u >> code) & 1u)) f |= 16u;           // codes 10,13,14,15
+    w[code >> 2] |= f << (8 * (code & 3));
+  }
+  MhlLut l;
+  l.lo0 = w[0]; l.lo1 = w[1]; l.hi0 = w[2]; l.hi1 = w[3];
+  return l;
 }
 
 }  // namespace epi
@@ -749,27 +887,29 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   b->last_ntiles = nt;
   if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; return EPI_OK; }
 
-  // pass 1: per-read stretch sizes and haplotype info
-  EPI_TRY(b->mhl_m.ensure(((size_t)b->nbytes + 64) * 2));
-  EPI_TRY(b->mhl_h.ensure((size_t)b->n * 4));
-  {
-    const int g = pick_mhl_group(st.max_len);
-    const int64_t threads = b->n * g;
-    const unsigned nb = (unsigned)((threads + 255) / 256);
-    prof_begin("mhl_rows", s);
-#define EPI_LAUNCH(GG)                                                                                          \
-  case GG:                                                                                                      \
-    hipLaunchKernelGGL((k_mhl_rows<GG>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->n, ctx_mask, (int32_t)hmin, \
-                       max_ooctx_meth_frac, b->mhl_m.as<uint16_t>(), b->mhl_h.as<int32_t>());                   \
-    break;
-    switch (g) {
-      EPI_LAUNCH(1) EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
-      default: return fail(EPI_ERR_ARG, "bad group size");
-    }
-#undef EPI_LAUNCH
-    prof_end("mhl_rows", s);
-    EPI_HIP(hipGetLastError());
+  // pass 1 workspace: per-read info, record table, records (grown on demand like the row pool)
+  const int g = pick_mhl_group(st.max_len);
+  const bool multi = g == 0;
+  const size_t nblkrec = multi ? (size_t)(b->nbytes >> MHL_BLK_SHIFT) + 2 * (size_t)b->n + 2 : (size_t)b->n;
+  EPI_TRY(b->mhl_h.ensure((size_t)b->n * 8));
+  EPI_TRY(b->mhl_blk.ensure(nblkrec * 8));
+  if (multi) EPI_TRY(b->mhl_cont.ensure(nblkrec * 4));
+  if (b->mhl_rec_cap == 0) {
+    b->mhl_rec_cap = (size_t)b->nbytes / 48 + (size_t)b->n + 64 * MHL_REGIONS;
+    EPI_TRY(b->mhl_m.ensure(b->mhl_rec_cap * sizeof(MhlRec)));
   }
+  EPI_TRY(b->mhl_cur.ensure((size_t)MHL_REGIONS * MHL_CUR_STRIDE * 8));
+  unsigned long long *rec_cursor = b->mhl_cur.as<unsigned long long>();
+  unsigned long long *rec_max = reinterpret_cast<unsigned long long *>(b->misc.as<uint32_t>() + 12);   // misc[12..13]
+
+  RowsArgs ra;
+  ra.xm = b->xm; ra.off = b->off; ra.n = b->n;
+  ra.lut = make_mhl_lut(ctx_mask);
+  ra.hmin = (int32_t)hmin; ra.max_oo = max_ooctx_meth_frac;
+  ra.rowinfo = b->mhl_h.as<int32_t>();
+  ra.blkrec = b->mhl_blk.as<uint2>();
+  ra.rec_cursor = rec_cursor;
+  ra.cont = multi ? b->mhl_cont.as<uint32_t>() : nullptr;
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
@@ -779,8 +919,11 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
 
   MhlArgs a;
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = nullptr;
-  a.m = b->mhl_m.as<uint16_t>();
   a.rowinfo = b->mhl_h.as<int32_t>();
+  a.blkrec = b->mhl_blk.as<uint2>();
+  a.multi = multi ? 1 : 0;
+  a.ablate = 0;
+  if (const char *env = getenv("EPIHIP_MHL_ABLATE")) a.ablate = atoi(env);
   a.tiles = b->tiles.as<Tile>();
   a.ctx_mask = ctx_mask; a.H = H;
   a.cursor = cursor;
@@ -788,6 +931,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.tile_base = b->tile_base.as<uint32_t>();
   a.heavy_rows = 16384;
   if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
+  if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // packed u16 counters: a base adds at most 2
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
   a.heavy_list = b->heavy_list.as<uint32_t>();
@@ -803,7 +947,30 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   b->mhl_ctx_mask = ctx_mask;
   uint32_t used_total[2] = {0, 0};
   const int tg = pick_mhl_tile_group(st.max_len);
-  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int attempt = 0; attempt < 3; attempt++) {
+    // pass 1: per-read haplotype size and stretch records
+    ra.recs = b->mhl_m.as<MhlRec>();
+    ra.rec_cap = (uint32_t)b->mhl_rec_cap;
+    EPI_HIP(hipMemsetAsync(rec_cursor, 0, (size_t)MHL_REGIONS * MHL_CUR_STRIDE * 8, s));
+    prof_begin("mhl_rows", s);
+    if (multi) {
+      hipLaunchKernelGGL(k_mhl_rows_multi, dim3((unsigned)((b->n + 3) / 4)), dim3(256), 0, s, ra);
+    } else {
+      const unsigned nb = (unsigned)((b->n * g + 255) / 256);
+#define EPI_LAUNCH(GG) case GG: hipLaunchKernelGGL((k_mhl_rows<GG>), dim3(nb), dim3(256), 0, s, ra); break;
+      switch (g) {
+        EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
+        default: return fail(EPI_ERR_ARG, "bad group size");
+      }
+#undef EPI_LAUNCH
+    }
+    prof_end("mhl_rows", s);
+    hipLaunchKernelGGL(k_mhl_cursor_max, dim3(1), dim3(MHL_REGIONS), 0, s, rec_cursor, rec_max);
+    EPI_HIP(hipGetLastError());
+
+    // pass 2
+    a.recs = ra.recs;
+    a.rec_cap = ra.rec_cap;
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_cov = b->pool_a.as<uint32_t>();
     a.pool_len = b->pool_d.as<double>();
@@ -816,8 +983,21 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    uint32_t host[8];
-    EPI_TRY(read_scalars(b, s, cursor, 32, host));         // misc[1..8]
+    uint32_t host[13];
+    EPI_TRY(read_scalars(b, s, cursor, 52, host));         // misc[1..13]
+    const unsigned long long rec_used = ((unsigned long long)host[12] << 32) | host[11];   // fullest region
+    if (rec_used > b->mhl_rec_cap / MHL_REGIONS) {         // record space ran out: the need is known now
+      if (attempt == 2) return fail(EPI_ERR_STATE, "stretch record overflow after regrow");
+      const unsigned long long want = (rec_used + rec_used / 16 + 64) * MHL_REGIONS;
+      if (want > 0xFFFFFFF0ull) return fail(EPI_ERR_NOMEM, "too many methylated stretches in one batch (%llu)", want);
+      b->mhl_rec_cap = (size_t)want;
+      EPI_TRY(b->mhl_m.ensure(b->mhl_rec_cap * sizeof(MhlRec)));
+      if (nshared > 0) {
+        EPI_HIP(hipMemsetAsync(a.shared_cnt, 0, (size_t)nshared * 16 * MHL_T * 4, s));
+        EPI_HIP(hipMemsetAsync(a.shared_sums, 0, (size_t)nshared * MHL_NSUM * 8, s));
+      }
+      continue;
+    }
     if (host[2] > 0) {                                     // pile-ups: split, reduce in HBM, emit, rescan
       const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
       EPI_TRY(b->heavy_slab.ensure((size_t)nheavy * 16 * MHL_T * 4));
@@ -836,7 +1016,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     used_total[0] = host[0];
     used_total[1] = host[1];
     if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
-    if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
+    if (attempt == 2) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
     EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));
     if (nshared > 0) {   // the rerun adds into the shared slabs again
       EPI_HIP(hipMemsetAsync(a.shared_cnt, 0, (size_t)nshared * 16 * MHL_T * 4, s));

@@ -5,11 +5,10 @@
 
 namespace epi {
 
-constexpr int CX_UN = 5;                      // lMHL: dword loads a lane keeps in flight per row (its accumulate loop is written for 5)
 #ifndef EPI_CX_NU
 #define EPI_CX_NU 10
 #endif
-constexpr int CX_NU = EPI_CX_NU;              // CX: dword loads a lane keeps in flight per row
+constexpr int CX_NU = EPI_CX_NU;              // dword loads a lane keeps in flight per row
 
 // nibble -> (counter slot, increment) as a 16-entry byte LUT for v_perm_b32: bits 0-2 = slot (see
 // enum in common.hpp), bits 4-5 = increment.
@@ -41,23 +40,38 @@ struct RowSlice {                         // the part of one row that falls insi
   uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
 };
 
+struct RowVals {                          // the columns of one candidate row, loaded
+  int32_t st, len, sd, ps;
+  int64_t o;
+  bool ok;                                // r < row_hi
+};
+
+__device__ __forceinline__ RowVals cx_load_row(const RowCols &a, const Tile &td, int r) {
+  RowVals v;
+  v.st = 0; v.len = 0; v.sd = 1; v.ps = 1; v.o = 0;
+  v.ok = r < td.row_hi;
+  if (v.ok) {
+    v.st = a.start[r];
+    v.o = a.off[r];
+    v.len = (int32_t)((uint32_t)a.off[r + 1] - (uint32_t)v.o);   // < 2^31 (checked by k_row_stats)
+    v.sd = a.strand[r];
+    v.ps = a.pass ? a.pass[r] : 1;
+  }
+  return v;
+}
+
 template <int T, int G, bool PK = false>
-__device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &td, int r, int sub, uint32_t *cnt) {
+__device__ __forceinline__ RowSlice cx_slice_of(const RowCols &a, const RowVals &v, const Tile &td, int sub, uint32_t *cnt) {
   RowSlice m;
   m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.lc4 = 0;
   m.mask_first = ~0u; m.mask_last = ~0u;
-  if (r < td.row_hi) {
-    const int32_t st = a.start[r];
-    const int64_t o = a.off[r];
-    const int32_t len = (int32_t)((uint32_t)a.off[r + 1] - (uint32_t)o);   // < 2^31 (checked by k_row_stats)
-    const int32_t sd = a.strand[r];
-    const int32_t ps = a.pass ? a.pass[r] : 1;
+  if (v.ok) {
     // row index of the tile's first position; |rel| < Lmax + T for a candidate row
-    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)st);
+    const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)v.st);
     const int32_t lo = rel > 0 ? rel : 0;
-    const int32_t hi = len < rel + T ? len : rel + T;
+    const int32_t hi = v.len < rel + T ? v.len : rel + T;
     if (hi > lo) {
-      const int64_t b0 = o + lo;
+      const int64_t b0 = v.o + lo;
       const int32_t e_lo = (int32_t)b0 & 3;              // slice bytes are e in [e_lo, e_hi) from the aligned start
       const int32_t e_hi = e_lo + (hi - lo);
       m.nd = (e_hi + 3) >> 2;
@@ -68,16 +82,21 @@ __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &t
       // rows (and row alignments d) they work on, so the 32 lanes always hit 32 different banks.
       const int d = lo - rel - e_lo;
       const int rot = ((int)((threadIdx.x & 31) >> 3) - d) & 3;
-      uint32_t *dst0 = cnt + (sd - 1) * (PK ? 4 : 8) * T + d + 4 * sub;
+      uint32_t *dst0 = cnt + (v.sd - 1) * (PK ? 4 : 8) * T + d + 4 * sub;
       m.rot8 = rot * 8;
 #pragma unroll
       for (int j = 0; j < 4; j++) m.dst[j] = dst0 + ((j + rot) & 3);
-      m.lc4 = ps == 0 ? 0x08080808u : 0u;
+      m.lc4 = v.ps == 0 ? 0x08080808u : 0u;
       m.mask_first = sub == 0 ? 0xFFFFFFFFu << (8 * e_lo) : ~0u;
       m.mask_last = 0xFFFFFFFFu >> (8 * (4 * m.nd - e_hi));
     }
   }
   return m;
+}
+
+template <int T, int G, bool PK = false>
+__device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &td, int r, int sub, uint32_t *cnt) {
+  return cx_slice_of<T, G, PK>(a, cx_load_row(a, td, r), td, sub, cnt);
 }
 
 // One dword (four bases) of a row into the LDS counters.  Every lane issues all four atomics: bytes
@@ -117,6 +136,32 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &
                                                          // the address with shift + and + add: one more VALU per base)
     const uint32_t inc = __builtin_amdgcn_ubfe(s4, 8 * j + 4, 2);
     atomicAdd(m.dst[j] + OFF + plane * T, inc);
+  }
+}
+
+// LDS dwords of one tile's counters: u32 [strand][8][T], or packed u16 pairs [strand][4][T] (tile_common.hpp)
+template <int T, bool PK> constexpr int cx_lds_dwords() { return (PK ? 8 : kCxPlanes) * T; }
+// waves per SIMD the kernel is compiled for: as many workgroups per CU as LDS (160 KiB) and 2048 threads allow
+template <int T, int WG, bool PK> constexpr int cx_waves_per_simd() {
+  const int by_lds = (160 * 1024) / (cx_lds_dwords<T, PK>() * 4 + 256), by_thr = 2048 / WG;
+  const int wgs = by_lds < by_thr ? by_lds : by_thr;
+  return wgs * WG / 256;
+}
+
+// Adds a tile's LDS counters into its dense u32 slab [16][T] in HBM (shared tiles, heavy tiles).
+template <int T, int WG, bool PK>
+__device__ __forceinline__ void cx_dump_slab(const uint32_t *cnt, int32_t *slab) {
+  uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
+  for (int i = threadIdx.x; i < cx_lds_dwords<T, PK>(); i += WG) {
+    const uint32_t v = cnt[i];
+    if (!v) continue;
+    if constexpr (PK) {
+      const int pl = i / T, p = i % T;                      // pl = strand*4 + pair -> planes 2*pl (low half), 2*pl+1
+      if (v & 0xFFFFu) atomicAdd(dst + (2 * pl) * T + p, v & 0xFFFFu);
+      if (v >> 16) atomicAdd(dst + (2 * pl + 1) * T + p, v >> 16);
+    } else {
+      atomicAdd(dst + i, v);
+    }
   }
 }
 

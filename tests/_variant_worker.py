@@ -1,4 +1,4 @@
-"""Child process of test_gpu_variants.py: CX reports of a few template sets against the oracle with whatever
+"""Child process of test_gpu_variants.py: CX and lMHL reports of a few template sets against the oracle with whatever
 EPIHIP_CX_* switches the parent put in the environment (they are read once per process)."""
 import os
 import sys
@@ -34,6 +34,10 @@ def main():
                 got = ea.rcpp_cx_report(bam, pv, ctx)
                 want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], pv, ctx)
                 H.assert_reports_equal(dict(got), want)
+            for hmax, hmin, moo in ((0, 0, 0.1), (3, 2, 1.0)):
+                got = ea.rcpp_mhl_report(bam, "Zz", hmax, hmin, moo)
+                want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, hmin, moo)
+                H.assert_reports_equal(dict(got), want, float_cols=("length", "lmhl"))
         finally:
             bam.close()
     print("variant ok", ea._lib.load().epi_tile_positions())
