@@ -386,7 +386,23 @@ struct MhlArgs {
   // tiles shared with other ranks of a sharded run: same two slabs, indexed by shared slot
   uint32_t *shared_cnt;
   unsigned long long *shared_sums;
+#ifdef EPI_MHL_CHECK
+  uint32_t *dbg;                          // diagnostic build: first out-of-range index {code, v0, v1, block, thread}
+  int64_t n, nbytes, nblkrec;
+#endif
 };
+
+#ifdef EPI_MHL_CHECK
+#define MHL_CHECK(cond, code, v0, v1)                                                                               \
+  if (!(cond)) {                                                                                                    \
+    if (atomicCAS(a.dbg, 0u, (uint32_t)(code)) == 0u) {                                                             \
+      a.dbg[1] = (uint32_t)(v0); a.dbg[2] = (uint32_t)(v1); a.dbg[3] = blockIdx.x; a.dbg[4] = threadIdx.x;          \
+    }                                                                                                               \
+    return;                                                                                                         \
+  }
+#else
+#define MHL_CHECK(cond, code, v0, v1)
+#endif
 
 // nibble -> flags of the rarely taken per-byte path: stray nibbles 3 / 4 / 8, whose counter slot IS the numerator /
 // denominator / haplotype-size sum in the reference (:190)
@@ -502,14 +518,31 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   int r = td.row_lo + wave * R + grp;
+  MHL_CHECK(td.row_lo >= 0 && td.row_hi <= a.n && td.row_hi >= td.row_lo, 9, td.row_lo, td.row_hi)
   MhlRow row = mhl_load_row(a, td, r);
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
     const MhlSlice cur = mhl_slice_of<G>(a, row, td, sub, L.cnt);
+    if (cur.rs.nd > 0) {
+      MHL_CHECK(r >= 0 && r < a.n, 1, r, cur.rs.nd)
+      MHL_CHECK(cur.sidx == 0 || cur.sidx == 1, 2, cur.sidx, r)
+      MHL_CHECK(cur.pf >= 0 && cur.pf < MHL_T && cur.pe > cur.pf && cur.pe <= MHL_T, 3, cur.pf, cur.pe)
+      MHL_CHECK(cur.rs.nd <= (MHL_T + 6) / 4 + 1, 4, cur.rs.nd, r)
+      MHL_CHECK(reinterpret_cast<const uint8_t *>(cur.rs.src) >= a.c.xm &&
+                reinterpret_cast<const uint8_t *>(cur.rs.src) - a.c.xm + 4 * (int64_t)(cur.rs.nd - sub) <= a.nbytes + 64, 5,
+                reinterpret_cast<const uint8_t *>(cur.rs.src) - a.c.xm, cur.rs.nd)
+#ifdef EPI_MHL_CHECK
+      if (sub < cur.rs.nd) {
+        const long rel0 = (cur.rs.dst[0] - L.cnt) - cur.sidx * 4 * MHL_T;      // first cell this lane adds to, within its strand's plane 0
+        MHL_CHECK(rel0 >= -3 && rel0 + 4 * ((cur.rs.nd - 1 - sub) / G) * G < MHL_T + 3, 7, rel0, cur.rs.nd * 1000 + sub)
+      }
+#endif
+    }
     uint32_t w[CX_NU];
 #pragma unroll
     for (int u = 0; u < CX_NU; u++) w[u] = sub + u * G < cur.rs.nd ? cur.rs.src[u * G] : 0u;
     const int rcur = r;
     const int64_t ocur = row.v.o;
+
     r += NW * R;
     row = mhl_load_row(a, td, r);                          // the next step's columns are in flight during this step's adds
     if (cur.rs.nd > 0) {
@@ -524,6 +557,7 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
       }
       const int64_t bi = a.multi ? (ocur >> MHL_BLK_SHIFT) + 2 * (int64_t)rcur : (int64_t)rcur;
       for (int32_t blk = cur.blk0; blk <= ((a.ablate & 2) ? -1 : cur.blk1); blk++) {   // the stretch pieces (and counted runs) near the tile
+        MHL_CHECK(bi + blk >= 0 && bi + blk < a.nblkrec, 8, bi + blk, blk)
         const uint2 br = a.blkrec[bi + blk];
         if ((uint64_t)br.x + br.y > a.rec_cap) continue;       // pass 1 ran out of record space: the caller reruns
         for (uint32_t k = (uint32_t)sub; k < br.y; k += G) {
@@ -922,6 +956,12 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.rowinfo = b->mhl_h.as<int32_t>();
   a.blkrec = b->mhl_blk.as<uint2>();
   a.multi = multi ? 1 : 0;
+#ifdef EPI_MHL_CHECK
+  EPI_TRY(b->diag.ensure(256));
+  a.dbg = b->diag.as<uint32_t>();
+  a.n = b->n; a.nbytes = b->nbytes; a.nblkrec = (int64_t)nblkrec;
+  EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
+#endif
   a.ablate = 0;
   if (const char *env = getenv("EPIHIP_MHL_ABLATE")) a.ablate = atoi(env);
   a.tiles = b->tiles.as<Tile>();
@@ -983,6 +1023,14 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+#ifdef EPI_MHL_CHECK
+    {
+      uint32_t d[8];
+      EPI_HIP(hipMemcpy(d, a.dbg, 32, hipMemcpyDeviceToHost));
+      if (d[0]) return fail(EPI_ERR_STATE, "lMHL index check %u failed: v0=%d v1=%d block=%u thread=%u (n=%lld nt=%d attempt=%d)", d[0],
+                            (int)d[1], (int)d[2], d[3], d[4], (long long)b->n, nt, attempt);
+    }
+#endif
     uint32_t host[13];
     EPI_TRY(read_scalars(b, s, cursor, 52, host));         // misc[1..13]
     const unsigned long long rec_used = ((unsigned long long)host[12] << 32) | host[11];   // fullest region
