@@ -86,7 +86,7 @@ struct epi_batch {
   epi::RowStats h_stats = {0, 0, 0, 0};   // host copy, fetched by the first report call (which raises the errors)
   epi::DevBuf scan_tmp;
   epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
-  epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e;
+  epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e, pool_f;
   epi::DevBuf misc;         // cursor etc.
   epi::DevBuf mhl_m, mhl_h, mhl_blk, mhl_cont, mhl_cur;   // lMHL pass 1: stretch records, per-read info, record table, block carries
   size_t mhl_rec_cap = 0;   // records that fit mhl_m

@@ -375,7 +375,7 @@ struct MhlArgs {
   const Tile *tiles;
   uint32_t ctx_mask, H;
   uint32_t *pool_key, *pool_cov;
-  double *pool_len, *pool_lmhl;
+  unsigned long long *pool_hs, *pool_nu, *pool_de;   // sum h, sum S(M), sum S(h) of the row's (pos,strand)
   uint32_t pool_cap;
   uint32_t *cursor, *tile_nrow, *tile_base;
   // ultra-deep tiles are set aside and split over many workgroups (as in the CX kernel)
@@ -579,45 +579,39 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
   }
 }
 
-// Rule, prefix sums of the difference arrays, ordered compaction of one tile (one position per thread).
+// Rule, prefix sums of the difference arrays, ordered compaction of one tile (one position per thread).  The pool rows
+// carry the three integer sums; the two divisions (:92-93) are done by k_mhl_gather, one row per lane.
 template <int WG, bool PK>
-__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, unsigned long long *s_w /* [6][NW] */,
-                                         uint32_t *s_scan) {
+__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, uint32_t *s_scan) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
-  static_assert(WG == T, "one position per thread in the emit phase");
+  constexpr int PER = T / 64;                             // positions per lane in the prefix-sum phase
+  static_assert(WG == T && NW >= 6, "one position per thread in the emit phase, one wavefront per difference array");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = threadIdx.x;
-  // six block-wide inclusive scans at once: wave scans, one exchange of the wave totals
-  unsigned long long v[6];
+  // in-place inclusive prefix sums of the six difference arrays: wavefront i takes array i (serial over a lane's
+  // PER consecutive positions, one 64-lane scan of the lane totals)
+  if (wave < 6) {
+    unsigned long long *arr = L.sums + wave * (T + 1) + lane * PER;
+    unsigned long long x[PER];
 #pragma unroll
-  for (int s = 0; s < 2; s++) {
-    v[3 * s + 0] = L.sums[MHL_DH + s * (T + 1) + p];
-    v[3 * s + 1] = L.sums[MHL_DD + s * (T + 1) + p];
-    v[3 * s + 2] = L.sums[MHL_DN + s * (T + 1) + p];
-  }
+    for (int j = 0; j < PER; j++) x[j] = arr[j];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
+    for (int j = 1; j < PER; j++) x[j] += x[j - 1];
+    unsigned long long inc = x[PER - 1];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const uint32_t lo = __shfl_up((uint32_t)v[i], d, 64);
-      const uint32_t hi = __shfl_up((uint32_t)(v[i] >> 32), d, 64);
-      if (lane >= d) v[i] += ((unsigned long long)hi << 32) | lo;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t lo = __shfl_up((uint32_t)inc, d, 64);
+      const uint32_t hi = __shfl_up((uint32_t)(inc >> 32), d, 64);
+      if (lane >= d) inc += ((unsigned long long)hi << 32) | lo;
     }
-  }
-  if (lane == 63) {
+    const unsigned long long ex = inc - x[PER - 1];
 #pragma unroll
-    for (int i = 0; i < 6; i++) s_w[i * NW + wave] = v[i];
+    for (int j = 0; j < PER; j++) arr[j] = x[j] + ex;
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    unsigned long long add = 0;
-    for (int w = 0; w < wave; w++) add += s_w[i * NW + w];
-    v[i] += add;
-  }
   uint32_t key[2], cov[2];
-  double len[2], lm[2];
+  unsigned long long hs[2], nu[2], de[2];
   bool ok[2];
   int nr = 0;
 #pragma unroll
@@ -648,8 +642,9 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     ok[s] = k != 0;
     key[s] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
     cov[s] = cc;                                                             // :90
-    len[s] = (double)v[3 * s + 0] / (double)(int)cc;                         // :92
-    lm[s] = (double)v[3 * s + 2] / (double)v[3 * s + 1];                     // :93
+    hs[s] = L.sums[MHL_DH + s * (T + 1) + p];                                // :92 numerator
+    nu[s] = L.sums[MHL_DN + s * (T + 1) + p];                                // :93 numerator
+    de[s] = L.sums[MHL_DD + s * (T + 1) + p];                                // :93 denominator
     nr += k != 0;
   }
   uint32_t inc = (uint32_t)nr;
@@ -679,8 +674,9 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
       if (ok[s]) {
         a.pool_key[w] = key[s];
         a.pool_cov[w] = cov[s];
-        a.pool_len[w] = len[s];
-        a.pool_lmhl[w] = lm[s];
+        a.pool_hs[w] = hs[s];
+        a.pool_nu[w] = nu[s];
+        a.pool_de[w] = de[s];
         w++;
       }
     }
@@ -703,7 +699,6 @@ __global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
   __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  __shared__ unsigned long long s_w[6 * NW];
   __shared__ uint32_t s_scan[NW + 2];
   const MhlLds L = mhl_lds(cnt_raw + kCxGuard, sums);
   const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
@@ -733,7 +728,7 @@ __global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
     return;
   }
   if (a.ablate & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
-  mhl_emit<WG, true>(a, tile, L, s_w, s_scan);
+  mhl_emit<WG, true>(a, tile, L, s_scan);
 }
 
 // One chunk of the candidate rows of one heavy tile -> added into that tile's slab in HBM.
@@ -767,12 +762,11 @@ __device__ __forceinline__ void mhl_emit_from_slab(const MhlArgs &a, int tile, c
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
   __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  __shared__ unsigned long long s_w[6 * NW];
   __shared__ uint32_t s_scan[NW + 2];
   for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
   __syncthreads();
-  mhl_emit<WG, false>(a, tile, mhl_lds(cnt, sums), s_w, s_scan);
+  mhl_emit<WG, false>(a, tile, mhl_lds(cnt, sums), s_scan);
 }
 
 template <int WG>
@@ -796,8 +790,9 @@ __global__ __launch_bounds__(WG) void k_mhl_emit_slab(MhlArgs a, const int32_t *
 __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
                                                      const uint32_t *__restrict__ tile_nrow, const uint32_t *__restrict__ tile_base,
                                                      int32_t ntiles, const uint32_t *__restrict__ pool_key,
-                                                     const uint32_t *__restrict__ pool_cov, const double *__restrict__ pool_len,
-                                                     const double *__restrict__ pool_lmhl, int32_t *__restrict__ o_rname,
+                                                     const uint32_t *__restrict__ pool_cov, const unsigned long long *__restrict__ pool_hs,
+                                                     const unsigned long long *__restrict__ pool_nu,
+                                                     const unsigned long long *__restrict__ pool_de, int32_t *__restrict__ o_rname,
                                                      int32_t *__restrict__ o_strand, int32_t *__restrict__ o_pos,
                                                      int32_t *__restrict__ o_ctx, int32_t *__restrict__ o_cov,
                                                      double *__restrict__ o_len, double *__restrict__ o_lmhl) {
@@ -815,9 +810,10 @@ __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ til
     o_strand[o] = 1 + (int32_t)((key >> 3) & 1u);
     o_pos[o] = (int32_t)(td.pos0 + (int64_t)(key >> 4));
     o_ctx[o] = (int32_t)(key & 7u);
-    o_cov[o] = (int32_t)pool_cov[src0 + i];
-    o_len[o] = pool_len[src0 + i];
-    o_lmhl[o] = pool_lmhl[src0 + i];
+    const uint32_t cov = pool_cov[src0 + i];
+    o_cov[o] = (int32_t)cov;                                                          // :90
+    o_len[o] = (double)pool_hs[src0 + i] / (double)(int)cov;                          // :92
+    o_lmhl[o] = (double)pool_nu[src0 + i] / (double)pool_de[src0 + i];                // :93
   }
 }
 
@@ -833,6 +829,7 @@ static int ensure_mhl_pool(epi_batch *b, size_t rows) {
   if (rows > b->pool_cap2 || !b->pool_d.p) {
     EPI_TRY(b->pool_d.ensure(rows * 8));
     EPI_TRY(b->pool_e.ensure(rows * 8));
+    EPI_TRY(b->pool_f.ensure(rows * 8));
     b->pool_cap2 = rows;
   }
   return EPI_OK;
@@ -1013,8 +1010,9 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     a.rec_cap = ra.rec_cap;
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_cov = b->pool_a.as<uint32_t>();
-    a.pool_len = b->pool_d.as<double>();
-    a.pool_lmhl = b->pool_e.as<double>();
+    a.pool_hs = b->pool_d.as<unsigned long long>();
+    a.pool_nu = b->pool_e.as<unsigned long long>();
+    a.pool_de = b->pool_f.as<unsigned long long>();
     a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
     EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
     EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
@@ -1112,8 +1110,9 @@ int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out) {
   a.shared_sums = reinterpret_cast<unsigned long long *>(b->d_mhl_sum_slab);
   a.pool_key = b->pool_key.as<uint32_t>();
   a.pool_cov = b->pool_a.as<uint32_t>();
-  a.pool_len = b->pool_d.as<double>();
-  a.pool_lmhl = b->pool_e.as<double>();
+  a.pool_hs = b->pool_d.as<unsigned long long>();
+  a.pool_nu = b->pool_e.as<unsigned long long>();
+  a.pool_de = b->pool_f.as<unsigned long long>();
   a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
   hipLaunchKernelGGL((k_mhl_emit_slab<MHL_WG>), dim3((unsigned)b->shared_keys.size()), dim3(MHL_WG), 0, s, a,
                      b->d_shared_owned.as<int32_t>(), b->d_slot_tile.as<int32_t>());
@@ -1139,7 +1138,8 @@ int epi_batch_mhl_fetch_dev(epi_batch *b, int32_t *const d_icols[5], double *con
   const unsigned nb = (unsigned)((b->last_ntiles + 3) / 4);
   hipLaunchKernelGGL(k_mhl_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
                      b->tile_nrow.as<uint32_t>(), b->tile_base.as<uint32_t>(), b->last_ntiles, b->pool_key.as<uint32_t>(),
-                     b->pool_a.as<uint32_t>(), b->pool_d.as<double>(), b->pool_e.as<double>(), d_icols[0], d_icols[1],
+                     b->pool_a.as<uint32_t>(), b->pool_d.as<unsigned long long>(), b->pool_e.as<unsigned long long>(),
+                     b->pool_f.as<unsigned long long>(), d_icols[0], d_icols[1],
                      d_icols[2], d_icols[3], d_icols[4], d_dcols[0], d_dcols[1]);
   EPI_HIP(hipGetLastError());
   return EPI_OK;
