@@ -101,23 +101,34 @@ __device__ __forceinline__ Chunk mhl_chunk(const uint8_t *__restrict__ xm, int64
   if (g0 + 16 < re) w1 = *reinterpret_cast<const uint4 *>(xm + g0 + 16);
   const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
   c.V = (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-  uint32_t Mb = 0, Nb = 0;
+  // bytes outside the row get flag 0: byte masks of the row within each dword (only edge chunks need them)
+  const bool edge = lo > 0 || hi < 32;
+  uint32_t f8[8], kacc = 0;
 #pragma unroll
   for (int d = 0; d < 8; d++) {
     const uint32_t c4 = ww[d] & 0x0F0F0F0Fu;
     const uint32_t lo3 = c4 & 0x07070707u;
     const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
-    const uint32_t f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
-                                             __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+    uint32_t f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
+                                       __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+    if (edge) {
+      int a = (int)lo - 4 * d, b = (int)hi - 4 * d;           // valid bytes [a, b) of this dword
+      a = a < 0 ? 0 : (a > 4 ? 4 : a);
+      b = b < 0 ? 0 : (b > 4 ? 4 : b);
+      const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
+      f &= bm;
+    }
+    f8[d] = f;
+    kacc |= f;
     c.U |= plane_nibble(f, 0) << (4 * d);
     c.L |= plane_nibble(f, 1) << (4 * d);
-    c.K |= plane_nibble(f, 2) << (4 * d);
-    Mb |= plane_nibble(f, 3) << (4 * d);
-    Nb |= plane_nibble(f, 4) << (4 * d);
+    c.oom = __builtin_amdgcn_sad_u8((f >> 3) & 0x01010101u, 0u, c.oom);
+    c.oou = __builtin_amdgcn_sad_u8((f >> 4) & 0x01010101u, 0u, c.oou);
   }
-  c.U &= c.V; c.L &= c.V; c.K &= c.V;
-  c.oom = __popc(Mb & c.V);
-  c.oou = __popc(Nb & c.V);
+  if (kacc & 0x04040404u) {                                   // skipped bytes are rare ('+'/'-', filler between mates)
+#pragma unroll
+    for (int d = 0; d < 8; d++) c.K |= plane_nibble(f8[d], 2) << (4 * d);
+  }
   return c;
 }
 
