@@ -28,7 +28,8 @@ class SynthParams(C.Structure):
 
 class BamOptions(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("min_mapq", "min_baseq", "skip_duplicates", "skip_secondary", "skip_qcfail",
-                                         "skip_supplementary", "trim5", "trim3", "paired", "nthreads")]
+                                         "skip_supplementary", "trim5", "trim3", "paired", "nthreads", "min_prob",
+                                         "highest_prob")]
 
 
 class Templates(C.Structure):

@@ -163,7 +163,8 @@ def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, h
     trim2 = (list(np.atleast_1d(trim)) * 2)[:2]                       # head(rep.int(trim, 2), 2)
     opt = _lib.BamOptions(int(min_mapq), int(min_baseq), int(bool(skip_duplicates)), int(bool(skip_secondary)),
                           int(bool(skip_qcfail)), int(bool(skip_supplementary)), int(trim2[0]), int(trim2[1]),
-                          -1 if paired is None else int(bool(paired)), max(int(nthreads), 1))
+                          -1 if paired is None else int(bool(paired)), max(int(nthreads), 1), int(min_prob),
+                          int(bool(highest_prob)))
     t = _lib.Templates()
     rc = lib.epi_preprocess_bam(os.path.expanduser(str(bam_file)).encode(), C.byref(opt), C.byref(t))
     if rc != _lib.EPI_OK:

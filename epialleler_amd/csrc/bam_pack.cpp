@@ -156,6 +156,128 @@ bool has_tag(const Rec &r, char a, char b) { bool pr; (void)aux_z(r, a, b, &pr);
 inline uint8_t ctx_idx(char c) { return (uint8_t)ctx_to_idx((unsigned char)c); }
 inline uint8_t seqi_shifted(const uint8_t *s, uint32_t i) { return (uint8_t)((s[i >> 1] << ((i & 1) << 2)) & 0xF0); }   // epialleleR.h:32
 
+
+// bam_aux_get for B-typed (array) tags: element type, count and a pointer to the first element; false if absent
+bool aux_b(const Rec &r, char a, char b, char *sub, uint32_t *count, const uint8_t **data) {
+  const uint8_t *p = r.aux;
+  while (p + 3 <= r.end) {
+    const bool hit = (char)p[0] == a && (char)p[1] == b;
+    const char ty = (char)p[2];
+    p += 3;
+    size_t adv = 0;
+    switch (ty) {
+      case 'A': case 'c': case 'C': adv = 1; break;
+      case 's': case 'S': adv = 2; break;
+      case 'i': case 'I': case 'f': adv = 4; break;
+      case 'Z': case 'H': {
+        const uint8_t *e = (const uint8_t *)memchr(p, 0, (size_t)(r.end - p));
+        if (!e || hit) return false;
+        p = e + 1;
+        continue;
+      }
+      case 'B': {
+        if (p + 5 > r.end) return false;
+        const char st = (char)p[0];
+        const uint32_t cnt = rd32(p + 1);
+        const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        if (p + 5 + (size_t)cnt * es > r.end) return false;
+        if (hit) { *sub = st; *count = cnt; *data = p + 5; return true; }
+        adv = 5 + (size_t)cnt * es;
+        break;
+      }
+      default: return false;
+    }
+    if (hit) return false;
+    p += adv;
+  }
+  return false;
+}
+
+// ---- long-read (MM/ML) records -------------------------------------------------------------------------------
+// The reference leaves the MM/ML tags to HTSlib (bam_parse_basemod / bam_next_basemod; Rhtslib, version not pinned in
+// DESCRIPTION).  HTSlib is not part of the reference tree, so this restates the published rules of the SAM tags
+// specification (SAMtags.pdf section 1.7 "Base modifications"):
+//   MM:Z:  ([ACGTUN][-+]([a-z]+|[0-9]+)[.?]?(,[0-9]+)*;)*   one entry per (canonical base, strand, modification codes);
+//          each number = how many bases of that canonical type to skip before the next modified one, counted along
+//          the read AS SEQUENCED: for a reverse-strand alignment from the end of SEQ, on the complemented base;
+//          base N counts every base; several one-letter codes in one entry share the positions.
+//   ML:B:C one probability (0..255) per listed position and code, in MM order, codes of an entry interleaved per
+//          position.  Without ML the probability is unknown (-1, as HTSlib reports it).
+// A ChEBI number n is carried as code -n (HTSlib's convention, which rcpp_read_bam.cpp:474 relies on for 27551).
+struct ModHit { int32_t pos; int32_t code; int32_t strand; int32_t qual; };
+
+inline int nt16_of(char c) {
+  switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8; case 'N': return 15; default: return -1; }
+}
+inline int nt16_complement(int c) { return c == 1 ? 8 : c == 8 ? 1 : c == 2 ? 4 : c == 4 ? 2 : c; }
+inline int seqi(const uint8_t *s, uint32_t i) { return (s[i >> 1] >> ((~i & 1) << 2)) & 0xF; }
+
+void parse_basemods(const Rec &r, const char *mm, bool has_ml, const uint8_t *ml, uint32_t n_ml, std::vector<ModHit> &hits) {
+  hits.clear();
+  const bool rev = (r.flag & 16) != 0;
+  const int32_t L = r.l_seq;
+  uint32_t ml_idx = 0;
+  const char *p = mm;
+  while (*p) {
+    const int base = nt16_of(*p);
+    if (base < 0) return;                                        // malformed: HTSlib gives up on the tag
+    p++;
+    if (*p != '+' && *p != '-') return;
+    const int32_t strand = *p == '-' ? 1 : 0;
+    p++;
+    int32_t codes[16];
+    int ncodes = 0;
+    if (*p >= '0' && *p <= '9') {                                // one ChEBI number
+      long v = 0;
+      while (*p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+      codes[ncodes++] = (int32_t)-v;
+    } else {
+      while (*p >= 'a' && *p <= 'z') { if (ncodes < 16) codes[ncodes++] = (int32_t)*p; p++; }
+    }
+    if (ncodes == 0) return;
+    if (*p == '.' || *p == '?') p++;                             // implicit / explicit mode: only listed bases matter here
+    const int target = rev ? nt16_complement(base) : base;
+    int32_t i = rev ? L - 1 : 0;                                 // next base of SEQ to look at, in sequencing order
+    const int32_t step = rev ? -1 : 1;
+    while (*p == ',') {
+      p++;
+      long skip = 0;
+      if (!(*p >= '0' && *p <= '9')) return;
+      while (*p >= '0' && *p <= '9') { skip = skip * 10 + (*p - '0'); p++; }
+      // advance to the (skip+1)-th base of the canonical type
+      int32_t found = -1;
+      while (i >= 0 && i < L) {
+        const bool match = target == 15 || seqi(r.seq, (uint32_t)i) == target;
+        const int32_t at = i;
+        i += step;
+        if (match) { if (skip == 0) { found = at; break; } skip--; }
+      }
+      if (found < 0) return;                                     // the tag points beyond the sequence
+      for (int k = 0; k < ncodes; k++) {
+        ModHit h;
+        h.pos = found; h.code = codes[k]; h.strand = strand;
+        h.qual = has_ml ? (ml_idx < n_ml ? (int32_t)ml[ml_idx] : -1) : -1;
+        ml_idx++;
+        hits.push_back(h);
+      }
+    }
+    if (*p != ';') return;
+    p++;
+  }
+}
+
+// cytosine context of query base i from the base and its two neighbours, keyed like the reference's 512-entry tables
+// (src/epialleleR.h:43-116) by the low three bits of the IUPAC letters: A=1 C=3 T=4 N=6 G=7, anything else gives '.'
+inline bool tri_ok(int c) { return c == 1 || c == 3 || c == 4 || c == 6 || c == 7; }
+inline char ctx_forward(int b0, int b1, int b2) {                // C at i: CG -> z, CHG -> x, CHH -> h
+  if (b0 != 3 || !tri_ok(b1) || !tri_ok(b2)) return '.';
+  return b1 == 7 ? 'z' : b2 == 7 ? 'x' : 'h';
+}
+inline char ctx_reverse(int b0, int b1, int b2) {                // G at i with (i-2, i-1, i): CG -> z, CHG -> x, CHH -> h
+  if (b2 != 7 || !tri_ok(b0) || !tri_ok(b1)) return '.';
+  return b1 == 3 ? 'z' : b0 == 3 ? 'x' : 'h';
+}
+
 struct Packed {
   std::vector<int32_t> rname, strand, start;
   std::vector<int64_t> off;          // template t owns bytes [off[t], off[t+1])
@@ -197,7 +319,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   memset(out, 0, sizeof(*out));
   epi_bam_options opt;
   if (opt_in) opt = *opt_in;
-  else { memset(&opt, 0, sizeof(opt)); opt.skip_secondary = opt.skip_qcfail = opt.skip_supplementary = 1; opt.paired = -1; opt.nthreads = 1; }
+  else { memset(&opt, 0, sizeof(opt)); opt.skip_secondary = opt.skip_qcfail = opt.skip_supplementary = 1; opt.paired = -1; opt.nthreads = 1; opt.min_prob = -1; opt.highest_prob = 1; }
   if (opt.trim5 < 0 || opt.trim3 < 0) return fail(EPI_ERR_ARG, "trim must be non-negative");
 
   std::vector<uint8_t> file, bam;
@@ -259,8 +381,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   if (!tXG && tYD) return fail(EPI_ERR_ARG, "No XG tags found (though YD tags are there)! BWA-meth alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
   if (!tXG && tZS) return fail(EPI_ERR_ARG, "No XG tags found (though ZS tags are there)! BSMAP alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
   if (!tXM && tXG) return fail(EPI_ERR_ARG, "No XM tags found! Was methylation called successfully? If not, make methylation calls using epialleleR::callMethylation. Exiting");
-  if (tMM) return fail(EPI_ERR_ARG, "long-read MM/ML alignment detected: not supported by this producer yet");
-  if (!(tXG && tXM)) return fail(EPI_ERR_ARG, "No known methylation tags found! Exiting");
+  if (!tMM && !(tXG && tXM)) return fail(EPI_ERR_ARG, "No known methylation tags found! Exiting");
   if (paired && !sorted) return fail(EPI_ERR_ARG, "BAM file seems to be paired-end but not sorted by name! Please sort using 'samtools sort -n -o out.bam in.bam'. Exiting");
   if (opt.paired >= 0 && (opt.paired != 0) != paired) return fail(EPI_ERR_ARG, "Expected endness is different from detected! Exiting");
 
@@ -273,7 +394,80 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   Packed P;
   P.off.push_back(0);
   const int trim5 = opt.trim5, trim3 = opt.trim3;
-  if (paired) {
+  if (tMM) {
+    // ---- rcpp_read_bam_mm_single (src/rcpp_read_bam.cpp:364-579) ----
+    static const char nt16_str[] = "=ACMGRSVTWYHKDBN";
+    std::vector<char> seq, xm[2];
+    std::vector<uint8_t> rs[2];
+    std::vector<ModHit> hits;
+    for (const Rec &r : recs) {
+      if ((r.flag & skip_flags) || (int)r.mapq < opt.min_mapq) continue;                        // :423-424
+      const int record_strand = (r.flag & 16) ? 1 : 0;                                          // :426
+      const int32_t qw = r.l_seq < 0 ? -r.l_seq : r.l_seq;                                      // :436
+      uint32_t width = 0;                                                                       // bam_cigar2rlen, :437
+      for (uint32_t i = 0; i < r.n_cigar; i++) {
+        const uint32_t c = rd32(r.cigar + 4 * i), op = c & 0xF;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) width += c >> 4;
+      }
+      rs[0].assign(width, 0xFB); rs[1].assign(width, 0xFB);                                     // :453-454
+      seq.assign((size_t)qw + 4, 'N');                                                          // :457-461 NN + SEQ + NN
+      for (int32_t i = 0; i < qw; i++) seq[(size_t)i + 2] = nt16_str[seqi(r.seq, (uint32_t)i)];
+      xm[0].resize((size_t)qw); xm[1].resize((size_t)qw);
+      for (int32_t i = 0; i < qw; i++) {                                                        // :464-467
+        xm[0][(size_t)i] = ctx_forward(seq[(size_t)i + 2] & 7, seq[(size_t)i + 3] & 7, seq[(size_t)i + 4] & 7);
+        xm[1][(size_t)i] = ctx_reverse(seq[(size_t)i] & 7, seq[(size_t)i + 1] & 7, seq[(size_t)i + 2] & 7);
+      }
+      bool strand_has_mods[2] = {false, false};
+      bool pmm = false;
+      const char *mm = aux_z(r, 'M', 'M', &pmm);
+      if (!mm) mm = aux_z(r, 'M', 'm', &pmm);
+      if (mm) {
+        char sub = 0; uint32_t n_ml = 0; const uint8_t *ml = nullptr;
+        bool has_ml = aux_b(r, 'M', 'L', &sub, &n_ml, &ml) || aux_b(r, 'M', 'l', &sub, &n_ml, &ml);
+        if (has_ml && sub != 'C' && sub != 'c') has_ml = false;
+        parse_basemods(r, mm, has_ml, ml, n_ml, hits);
+        std::stable_sort(hits.begin(), hits.end(), [](const ModHit &x, const ModHit &y) { return x.pos < y.pos; });
+        for (size_t a0 = 0; a0 < hits.size();) {                                                // one query position at a time, :469
+          size_t a1 = a0;
+          int ismeth[2] = {0, 0}, meth_prob[2] = {-2, -2}, max_other[2] = {-2, -2};             // :470-472
+          for (; a1 < hits.size() && hits[a1].pos == hits[a0].pos; a1++) {
+            const ModHit &h = hits[a1];
+            if (h.code == 'm' || h.code == -27551) { ismeth[h.strand] = 1; meth_prob[h.strand] = h.qual; }   // :474-476
+            else if (max_other[h.strand] < h.qual) max_other[h.strand] = h.qual;                             // :477-479
+          }
+          const int32_t mod_pos = hits[a0].pos;
+          for (int sidx = 0; sidx < 2; sidx++) {                                                // :481-490
+            const int cs = record_strand > sidx ? record_strand - sidx : sidx - record_strand;
+            if (ismeth[sidx] && meth_prob[sidx] >= opt.min_prob && (!opt.highest_prob || meth_prob[sidx] > max_other[sidx]) &&
+                xm[cs][(size_t)mod_pos] > 'A') {
+              xm[cs][(size_t)mod_pos] &= (char)0xDF;
+              strand_has_mods[cs] = true;
+            }
+          }
+          a0 = a1;
+        }
+      }
+      uint32_t dest_end = 0;
+      EPI_TRY(apply_cigar(r, 0, [&](uint32_t qpos, uint32_t dpos, uint32_t len) {              // :494-531
+        for (uint32_t j = 0; j < len; j++)
+          if ((int)r.qual[qpos + j] >= opt.min_baseq) {
+            const uint8_t hi = seqi_shifted(r.seq, qpos + j);
+            rs[0][dpos + j] = (uint8_t)(hi | ctx_idx(xm[0][qpos + j]));
+            rs[1][dpos + j] = (uint8_t)(hi | ctx_idx(xm[1][qpos + j]));
+          }
+      }, &dest_end));
+      strand_has_mods[record_strand] = true;                                                    // :534
+      for (int sidx = 0; sidx < 2; sidx++) {
+        if (!strand_has_mods[sidx]) continue;
+        P.rname.push_back(r.tid + 1);                                                           // :537-541
+        P.strand.push_back(sidx + 1);
+        P.start.push_back(r.pos + trim5 + 1);
+        const int keep = (int)dest_end - (trim5 + trim3);
+        if (keep > 0) P.bytes.insert(P.bytes.end(), rs[sidx].begin() + trim5, rs[sidx].begin() + trim5 + keep);
+        P.off.push_back((int64_t)P.bytes.size());
+      }
+    }
+  } else if (paired) {
     skip_flags |= 8;
     const uint8_t q0 = (uint8_t)(opt.min_baseq - (opt.min_baseq > 0 ? 1 : 0));   // src/rcpp_read_bam.cpp:30,57
     std::vector<uint8_t> tq(8192, q0), ts(8192, 0xFB);

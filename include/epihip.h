@@ -105,6 +105,9 @@ typedef struct {
   int32_t trim5, trim3;
   int32_t paired;      /* -1 = detect as .checkBam does; 0/1 = expected endness (error if different) */
   int32_t nthreads;    /* BGZF inflate threads (>=1) */
+  /* long-read (MM/ML) alignments only, rcpp_read_bam_mm_single (src/rcpp_read_bam.cpp:364-372): */
+  int32_t min_prob;    /* minimum ML probability of a 5mC call (R default -1)                            */
+  int32_t highest_prob;/* the 5mC probability must be the highest of all modifications at the base (TRUE) */
 } epi_bam_options;
 
 typedef struct {       /* library-owned; release with epi_templates_free */

@@ -42,7 +42,8 @@ def _parse_aux(buf):
         elif typ == "B":
             sub = chr(buf[p])
             cnt = struct.unpack_from("<i", buf, p + 1)[0]
-            tags[tag] = (typ, None)
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+            tags[tag] = (typ, (sub, struct.unpack_from("<%d%s" % (cnt, fmt), buf, p + 5)))
             p += 5 + cnt * size[sub]
         else:
             tags[tag] = (typ, bytes(buf[p:p + size[typ]]))
@@ -226,8 +227,140 @@ def _pack_single(recs, min_mapq, min_baseq, skip_flags, trim5, trim3):
     return rname, strand, start, seqs, nrecs
 
 
+
+# ---- long-read (MM/ML) records: rcpp_read_bam_mm_single, src/rcpp_read_bam.cpp:364-579 --------------------------
+# HTSlib (bam_parse_basemod / bam_next_basemod) is a dependency outside the reference tree; the tag rules restated
+# here are those of the SAM tags specification, section 1.7 (see csrc/bam_pack.cpp for the summary).
+
+NT16_STR = "=ACMGRSVTWYHKDBN"
+_NT16 = {"A": 1, "C": 2, "G": 4, "T": 8, "U": 8, "N": 15}
+_COMP = {1: 8, 8: 1, 2: 4, 4: 2}
+
+
+def parse_basemods(codes4, flag, mm, ml):
+    """[(query position, modification code, strand 0/1, probability or -1)] in MM order.
+    codes4: 4-bit base codes of SEQ as stored; a ChEBI number n is reported as -n."""
+    hits = []
+    rev = bool(flag & 16)
+    L = len(codes4)
+    k = 0
+    for entry in mm.split(";"):
+        if not entry:
+            continue
+        base = _NT16.get(entry[0])
+        if base is None or len(entry) < 3 or entry[1] not in "+-":
+            break
+        strand = 1 if entry[1] == "-" else 0
+        head, _, tail = entry[2:].partition(",")
+        head = head.rstrip(".?")
+        if not head:
+            break
+        codes = [-int(head)] if head[0].isdigit() else [ord(ch) for ch in head]
+        target = _COMP.get(base, base) if rev else base
+        order = range(L - 1, -1, -1) if rev else range(L)
+        typed = [i for i in order if target == 15 or codes4[i] == target]     # bases of the canonical type, as sequenced
+        at = 0
+        bad = False
+        for d in (tail.split(",") if tail else []):
+            at += int(d)
+            if at >= len(typed):
+                bad = True
+                break
+            for c in codes:
+                hits.append((typed[at], c, strand, (ml[k] if k < len(ml) else -1) if ml is not None else -1))
+                k += 1
+            at += 1
+        if bad:
+            break
+    return hits
+
+
+def _tri_ok(c):
+    return c in (1, 3, 4, 6, 7)
+
+
+def _ctx_forward(b0, b1, b2):
+    if b0 != 3 or not _tri_ok(b1) or not _tri_ok(b2):
+        return "."
+    return "z" if b1 == 7 else ("x" if b2 == 7 else "h")
+
+
+def _ctx_reverse(b0, b1, b2):
+    if b2 != 7 or not _tri_ok(b0) or not _tri_ok(b1):
+        return "."
+    return "z" if b1 == 3 else ("x" if b0 == 3 else "h")
+
+
+def _pack_mm_single(recs, min_mapq, min_baseq, min_prob, highest_prob, skip_flags, trim5, trim3):
+    rname, strand, start, seqs = [], [], [], []
+    nrecs = 0
+    for r in recs:
+        nrecs += 1
+        if (r.flag & skip_flags) or r.mapq < min_mapq:                   # :423-424
+            continue
+        rstrand = 1 if (r.flag & 16) else 0                              # :426
+        L = r.qual.size
+        idx = np.arange(L)
+        codes4 = ((r.seq[idx >> 1] >> ((~idx & 1) << 2)) & 0xF).astype(np.int64) if L else np.zeros(0, np.int64)
+        seq = "NN" + "".join(NT16_STR[c] for c in codes4) + "NN"        # :457-461
+        lo = [ord(ch) & 7 for ch in seq]
+        xm = [[_ctx_forward(lo[i + 2], lo[i + 3], lo[i + 4]) for i in range(L)],      # :464-467
+              [_ctx_reverse(lo[i], lo[i + 1], lo[i + 2]) for i in range(L)]]
+        has_mods = [False, False]
+        mmt = r.tags.get("MM") or r.tags.get("Mm")
+        if mmt is not None and mmt[0] == "Z":
+            mlt = r.tags.get("ML") or r.tags.get("Ml")
+            ml = list(mlt[1][1]) if (mlt is not None and mlt[0] == "B" and mlt[1][0] in "Cc") else None
+            hits = parse_basemods(list(codes4), r.flag, mmt[1].decode("latin1"), ml)
+            bypos = {}
+            for h in hits:
+                bypos.setdefault(h[0], []).append(h)
+            for pos in sorted(bypos):                                    # :469-491
+                ismeth, prob, other = [0, 0], [-2, -2], [-2, -2]
+                for (_p, code, st, q) in bypos[pos]:
+                    if code == ord("m") or code == -27551:
+                        ismeth[st] = 1
+                        prob[st] = q
+                    elif other[st] < q:
+                        other[st] = q
+                for st in (0, 1):
+                    cs = abs(rstrand - st)
+                    if ismeth[st] and prob[st] >= min_prob and (not highest_prob or prob[st] > other[st]) and xm[cs][pos] > "A":
+                        xm[cs][pos] = xm[cs][pos].upper()
+                        has_mods[cs] = True
+        width = sum((int(c) >> 4) for c in r.cigar if (int(c) & 0xF) in (0, 2, 3, 7, 8))
+        rs = [np.full(width, FILLER, np.uint8), np.full(width, FILLER, np.uint8)]
+        qpos = dpos = 0
+        for c in r.cigar:                                                # :494-531
+            op, ln = int(c) & 0xF, int(c) >> 4
+            if op in (0, 7, 8):
+                for j in range(ln):
+                    if r.qual[qpos + j] >= min_baseq:
+                        hi = int(codes4[qpos + j]) << 4
+                        for st in (0, 1):
+                            rs[st][dpos + j] = hi | int(ctx_to_idx(ord(xm[st][qpos + j])))
+                qpos += ln
+                dpos += ln
+            elif op in (1, 4):
+                qpos += ln
+            elif op in (2, 3):
+                dpos += ln
+            elif op in (5, 6, 9):
+                pass
+            else:
+                raise ValueError("Unknown CIGAR operation")
+        has_mods[rstrand] = True                                         # :534
+        for st in (0, 1):
+            if has_mods[st]:
+                rname.append(r.tid + 1)
+                strand.append(st + 1)
+                start.append(r.pos + trim5 + 1)
+                seqs.append(rs[st][trim5:trim5 + max(dpos - (trim5 + trim3), 0)].copy())
+    return rname, strand, start, seqs, nrecs
+
+
 def preprocess_bam(path, paired=None, min_mapq=0, min_baseq=0, skip_duplicates=False,
-                   skip_secondary=True, skip_qcfail=True, skip_supplementary=True, trim=0):
+                   skip_secondary=True, skip_qcfail=True, skip_supplementary=True, trim=0, min_prob=-1, highest_prob=True):
     """preprocessBam() for short-read XG/XM BAMs (R/preprocessBam.R:197-237).
 
     Returns a dict with sorted SoA columns: xm (uint8, concatenated in row
@@ -247,7 +380,11 @@ def preprocess_bam(path, paired=None, min_mapq=0, min_baseq=0, skip_duplicates=F
     skip_flags += 512 if skip_qcfail else 0
     skip_flags += 1024 if skip_duplicates else 0
     skip_flags += 2048 if skip_supplementary else 0
-    if chk["paired"]:
+    long_read = any(("MM" in r.tags or "Mm" in r.tags) for r in recs[:1024])   # R/internal.R:104
+    if long_read:
+        rname, strand, start, seqs, nrecs = _pack_mm_single(recs, min_mapq, min_baseq, min_prob, highest_prob, skip_flags,
+                                                            trim5, trim3)
+    elif chk["paired"]:
         skip_flags += 8
         rname, strand, start, seqs, nrecs = _pack_paired(recs, min_mapq, min_baseq, skip_flags, trim5, trim3)
     else:

@@ -6,6 +6,7 @@ Run in the build container (needs /root/reference):
     python tests/golden/make_expected.py
 Sources (reference inst/unitTests/):
     test_generateCytosineReport.R:1-260, test_generateMhlReport.R:1-123,
+    test_generateCytosineReport.R:262-433 (long-read MM/ML cases: inputs and expected tables),
     test_simulateBam.R:53-87, test_generateBedReport.R:12-83,
     test_preprocessBam.R:11-15
 plus the survey-time probe outputs recorded in SURVEY.md section 8c.
@@ -57,12 +58,91 @@ def collect(fn):
     return out
 
 
+
+def long_read_cases():
+    """test_generateCytosineReport.R:262-433: simulateBam() inputs (flag, seq, Mm, Ml), the generateCytosineReport
+    options and every expected value of the long-read (MM/ML) section, in file order."""
+    src = open(os.path.join(REF, "test_generateCytosineReport.R")).read()
+    sec = src[src.index("### long-read"):]
+    sec = sec[:sec.index("  # simulateBam(")]
+
+    def call_args(text, start):
+        """text[start] is just after '('; returns (argument string, index after the closing paren)."""
+        depth, i = 1, start
+        while depth:
+            depth += text[i] in "([" 
+            depth -= text[i] in ")]"
+            i += 1
+        return text[start:i - 1], i
+
+    def split_args(a):
+        out, cur, depth, q = [], [], 0, False
+        for ch in a:
+            if ch == '"':
+                q = not q
+            if not q:
+                depth += ch in "(["
+                depth -= ch in ")]"
+                if ch == "," and depth == 0:
+                    out.append("".join(cur).strip())
+                    cur = []
+                    continue
+            cur.append(ch)
+        out.append("".join(cur).strip())
+        return out
+
+    def ints(t):
+        m = re.match(r"^(?:as\.integer\()?rep\.int\((-?\d+), *(\d+)\)\)?$", t.strip())
+        if m:
+            return [int(m.group(1))] * int(m.group(2))
+        return [int(x) for x in re.findall(r"-?\d+", t)]
+
+    def strs(t):
+        return re.findall(r'"([^"]*)"', t)
+
+    def table(t):
+        inner, _ = call_args(t, t.index("(") + 1)
+        cols = {}
+        for a in split_args(inner):
+            k, v = a.split("=", 1)
+            k = k.strip()
+            if k == "strand":
+                cols[k] = strs(split_args(v[v.index("(") + 1:])[0])
+            elif k == "context":
+                cols[k] = ints(split_args(v[v.index("(") + 1:])[0])
+            else:
+                cols[k] = ints(v)
+        return cols
+
+    cases, cur, opts = [], None, None
+    for m in re.finditer(r"simulateBam\(|generateCytosineReport\(|RUnit::checkEquals\(", sec):
+        a, _ = call_args(sec, m.end())
+        a = re.sub(r"\s+", " ", a)
+        if m.group(0).startswith("simulateBam"):
+            kv = dict(x.split("=", 1) for x in split_args(a))
+            kv = {k.strip(): v.strip() for k, v in kv.items()}
+            ml = [ints(x) for x in split_args(call_args(kv["Ml"], kv["Ml"].index("(") + 1)[0])]
+            cur = {"flag": ints(kv["flag"]), "seq": strs(kv["seq"]), "pos": ints(kv["pos"]), "Mm": strs(kv["Mm"]), "Ml": ml,
+                   "reports": []}
+            cases.append(cur)
+        elif m.group(0).startswith("generateCytosineReport"):
+            kv = dict(x.split("=", 1) for x in split_args(a)[1:])
+            opts = {"min_prob": int(kv.get("min.prob", "-1")), "highest_prob": kv.get("highest.prob", "TRUE").strip() == "TRUE",
+                    "report_context": strs(kv["report.context"])[0], "checks": []}
+            cur["reports"].append(opts)
+        else:
+            expr, val = split_args(a)[:2]
+            opts["checks"].append({"expr": expr, "value": table(val) if val.startswith("data.table") else ints(val)})
+    return cases
+
+
 exp = {
     "_source": "reference inst/unitTests/*.R (RUnit known-answer values), extracted by tests/golden/make_expected.py",
     "generateCytosineReport": collect("test_generateCytosineReport.R"),
     "generateMhlReport": collect("test_generateMhlReport.R"),
     "simulateBam": collect("test_simulateBam.R"),
     "generateBedReport": collect("test_generateBedReport.R"),
+    "longRead": long_read_cases(),
     # Recorded at survey time from the unmodified reference objects (SURVEY.md 8c);
     # not reproducible in this image (reference unbuildable), kept as extra pins.
     "survey_probe": {

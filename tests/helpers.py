@@ -119,3 +119,52 @@ def assert_reports_equal(a, b, float_cols=()):
                 np.array_equal(a[k], b[k], equal_nan=True), k
         else:
             assert np.array_equal(a[k], b[k]), k
+
+
+# ---- a minimal BAM writer for the tests (what the reference's simulateBam() gives its long-read tests) ----------
+
+def write_bam(path, records, refs=(("chrS", 1000),)):
+    """records: dicts with seq (str), flag, pos (1-based), optional qname, mapq, cigar [(op, len)], qual (bytes or int),
+    tid, tags {name: str (Z) | list of ints (B:C)}.  Defaults follow R/internal.R:296-398: mapq 60, cigar <len>M,
+    quality 'F'."""
+    import struct
+    import zlib
+    nt16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    body = bytearray(b"BAM\1")
+    text = "@HD\tVN:1.0\tSO:unknown\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    body += struct.pack("<i", len(text)) + text.encode()
+    body += struct.pack("<i", len(refs))
+    for name, ln in refs:
+        body += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    for k, r in enumerate(records):
+        seq = r["seq"]
+        n = len(seq)
+        qname = (r.get("qname") or ("q%06d" % k)).encode() + b"\0"
+        cigar = r.get("cigar") or [(0, n)]
+        qual = r.get("qual", 37)
+        qual = bytes([qual]) * n if isinstance(qual, int) else bytes(qual)
+        packed = bytearray((n + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= nt16[ch] << (4 if (i & 1) == 0 else 0)
+        aux = bytearray()
+        for tag, val in (r.get("tags") or {}).items():
+            if isinstance(val, str):
+                aux += tag.encode() + b"Z" + val.encode() + b"\0"
+            else:
+                aux += tag.encode() + b"BC" + struct.pack("<i", len(val)) + bytes(val)
+        core = struct.pack("<iiBBHHHiiii", r.get("tid", 0), r["pos"] - 1, len(qname), r.get("mapq", 60), 4680, len(cigar),
+                           r.get("flag", 0), n, -1, -1, 0)
+        rec = core + qname + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar) + bytes(packed) + qual + bytes(aux)
+        body += struct.pack("<i", len(rec)) + rec
+
+    def block(data):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(bytes(data)) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(bytes(data)) & 0xFFFFFFFF, len(data)))
+
+    with open(path, "wb") as f:
+        for i in range(0, len(body), 60000):
+            f.write(block(body[i:i + 60000]))
+        f.write(block(b""))
+    return path

@@ -302,3 +302,18 @@ def test_host_drop_in_entry_points(ea):
     # error path: NULL offsets
     assert lib.epi_threshold_reads(None, None, 1, b"Z", b"z", b"", b"", 0, 0.0, 0.0, vp(out)) == 1
     assert b"bad arguments" in lib.epi_last_error()
+
+
+# ---- long-read (MM/ML) BAM file -> report on the GPU, against the reference's own expected tables ----------------
+
+def test_long_read_bam_file_to_report(ea, tmp_path):
+    import test_long_read as LR
+    for case in LR.CASES:
+        LR.check_case(case, lambda p, **kw: ea.preprocessBam(p, **kw),
+                      lambda bam, ctx: dict(ea.rcpp_cx_report(bam, None, ctx)), tmp_path)
+    # and the R-level entry point with its long-read arguments (R/generateCytosineReport.R:164-208)
+    case = LR.CASES[0]
+    path = LR.case_bam(case, str(tmp_path / "lr0.bam"))
+    rep = ea.generateCytosineReport(path, threshold_reads=False, report_context="CX", min_prob=160, highest_prob=False)
+    want = case["reports"][1]["checks"][0]["value"]
+    assert rep["meth"].tolist() == want["meth"] and rep["pos"].tolist() == want["pos"]
