@@ -180,6 +180,8 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(bam, wl, min(args.cpu_sample, rows), np)
+        else:
+            out["cpu_baseline"] = None                   # --cpu-sample 0 / N > 1: not timed in this run
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
