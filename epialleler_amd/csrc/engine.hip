@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 namespace epi {
 
@@ -161,8 +163,25 @@ int epi_engine_device(const epi_engine *e) { return e ? e->device : -1; }
 
 // Host -> HBM through two pinned staging buffers: the CPU fills buffer k+1
 // while the DMA engine drains buffer k (hipMemcpyAsync on the copy stream).
+// memcpy into a pinned staging buffer with a few threads: one core copies ~12 GB/s, the link takes ~55
+static void parallel_memcpy(void *dst, const void *src, size_t len) {
+  static const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned k = len < (4u << 20) ? 1u : (hw >= 8 ? 4u : hw >= 4 ? 2u : 1u);
+  if (k == 1) { memcpy(dst, src, len); return; }
+  const size_t part = (len / k + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  for (unsigned i = 1; i < k; i++) {
+    const size_t o = part * i;
+    if (o >= len) break;
+    const size_t l = o + part > len ? len - o : part;
+    th.emplace_back([=]() { memcpy(static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, l); });
+  }
+  memcpy(dst, src, part < len ? part : len);
+  for (auto &t : th) t.join();
+}
+
 static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t bytes) {
-  const size_t chunk = 32u << 20;
+  const size_t chunk = 64u << 20;
   if (!eng->pinned[0]) {
     for (int i = 0; i < 2; i++) {
       EPI_HIP(hipHostMalloc(&eng->pinned[i], chunk, hipHostMallocDefault));
@@ -175,7 +194,7 @@ static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t
   while (done < bytes) {
     size_t len = bytes - done < chunk ? bytes - done : chunk;
     EPI_HIP(hipEventSynchronize(eng->pinned_done[k]));   // buffer k free again (no-op before first use)
-    memcpy(eng->pinned[k], static_cast<const char *>(h_src) + done, len);
+    parallel_memcpy(eng->pinned[k], static_cast<const char *>(h_src) + done, len);
     EPI_HIP(hipMemcpyAsync(static_cast<char *>(d_dst) + done, eng->pinned[k], len, hipMemcpyHostToDevice, eng->copy_stream));
     EPI_HIP(hipEventRecord(eng->pinned_done[k], eng->copy_stream));
     done += len;
