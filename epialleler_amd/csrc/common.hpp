@@ -103,6 +103,8 @@ struct epi_batch {
   // multi-GPU shared tiles
   std::vector<int64_t> shared_keys;
   std::vector<int32_t> shared_owned;
+  std::vector<int64_t> dev_shared_keys;      // what d_shared_keys / d_shared_owned currently hold
+  std::vector<int32_t> dev_shared_owned;
   epi::DevBuf d_shared_keys, d_shared_owned, d_slot_tile;
   int32_t *d_slab = nullptr;
   int32_t *d_mhl_cnt_slab = nullptr;     // lMHL shared tiles: counters and 64-bit sums

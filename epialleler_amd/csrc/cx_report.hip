@@ -586,6 +586,13 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
   EPI_HIP(hipSetDevice(b->eng->device));
   b->shared_keys.assign(h_keys, h_keys + nshared);
   b->shared_owned.assign(h_owned, h_owned + nshared);
+  // a sharded run attaches the same keys for every report: skip the copies when the device already holds them
+  if (nshared > 0 && b->dev_shared_keys == b->shared_keys && b->dev_shared_owned == b->shared_owned) {
+    b->d_slab = d_slab;
+    b->d_mhl_cnt_slab = nullptr;
+    b->d_mhl_sum_slab = nullptr;
+    return EPI_OK;
+  }
   b->d_slab = nshared > 0 ? d_slab : nullptr;
   b->d_mhl_cnt_slab = nullptr;
   b->d_mhl_sum_slab = nullptr;
@@ -594,6 +601,8 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
     EPI_TRY(b->d_shared_owned.ensure((size_t)nshared * 4));
     EPI_HIP(hipMemcpy(b->d_shared_keys.p, h_keys, (size_t)nshared * 8, hipMemcpyHostToDevice));
     EPI_HIP(hipMemcpy(b->d_shared_owned.p, h_owned, (size_t)nshared * 4, hipMemcpyHostToDevice));
+    b->dev_shared_keys = b->shared_keys;
+    b->dev_shared_owned = b->shared_owned;
   }
   return EPI_OK;
 }

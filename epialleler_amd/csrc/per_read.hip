@@ -41,6 +41,10 @@ static int make_lut(const char *s, ClassLut *out) {
 
 template <int NCLS>
 __device__ __forceinline__ void acc_dword(uint32_t w, uint32_t mask, const Luts &L, uint32_t (&acc)[NCLS]) {
+#ifdef EPI_PR_NOALU
+  acc[0] |= w & mask;                                   // timing experiment: loads only
+  return;
+#endif
   const uint32_t v = w & 0x0F0F0F0Fu;                 // unpack_ctx_idx, four codes
   const uint32_t lo3 = v & 0x07070707u;
   // per byte: take the codes-8..15 lookup when bit 3 of the code is set (selector j + 4*bit3)

@@ -97,7 +97,11 @@ class HipShardEngine:
     def cx_accumulate(self, pass_, ctx, keys, owned):
         torch = self.torch
         T = self.tile_positions()
-        self._slab = torch.zeros(max(keys.size, 1) * 16 * T, dtype=torch.int32, device=self.device)
+        want = max(keys.size, 1) * 16 * T
+        if self._slab is None or self._slab.numel() != want:
+            self._slab = torch.zeros(want, dtype=torch.int32, device=self.device)
+        else:
+            self._slab.zero_()
         keys = np.ascontiguousarray(keys, np.int64)
         owned = np.ascontiguousarray(owned, np.int32)
         _lib.check(self.lib.epi_batch_cx_set_shared(
@@ -164,11 +168,15 @@ class HipShardEngine:
 
 
 def _exchange_ranges(engine, kind, group):
-    """all_gather of every rank's (first,last) tile key -> (ranges, world, rank)."""
+    """all_gather of every rank's (first,last) tile key -> (ranges, world, rank).  The shards and the tile grid do not
+    change, so the exchange is done once per (engine, tile grid, group) and remembered on the engine."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    memo = engine.__dict__.setdefault("_all_ranges", {})
+    if (kind, id(group), world) in memo:
+        return memo[(kind, id(group), world)], world, rank
     first, last = engine.key_range(kind) if kind != "cx" else engine.key_range()
     if world > 1:
         mine = torch.tensor([first, last], dtype=torch.int64, device=engine.device)
@@ -177,6 +185,7 @@ def _exchange_ranges(engine, kind, group):
         ranges = [tuple(int(v) for v in t.cpu().tolist()) for t in allr]
     else:
         ranges = [(first, last)]
+    memo[(kind, id(group), world)] = ranges
     return ranges, world, rank
 
 
@@ -242,17 +251,8 @@ def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None):
     when gather=True, else this rank's rows (rank order = table order)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ranges, world, rank = _exchange_ranges(engine, "cx", group)
     dev = engine.device
-    first, last = engine.key_range()
-    if world > 1:
-        mine = torch.tensor([first, last], dtype=torch.int64, device=dev)
-        allr = [torch.empty(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(allr, mine, group=group)
-        ranges = [tuple(int(v) for v in t.cpu().tolist()) for t in allr]
-    else:
-        ranges = [(first, last)]
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
     slab = engine.cx_accumulate(pass_, ctx, keys, owned)
