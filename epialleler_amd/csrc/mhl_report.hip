@@ -10,7 +10,7 @@
 // the byte's (pos,strand).  All three sums are constant over intervals of a read,
 // so nothing is stored per byte here:
 //
-//  k_mhl_rows    G lanes own a read, 32 bytes per lane.  Bit masks per lane (member,
+//  k_mhl_rows    G lanes own a read, 32 to 64 bytes per lane.  Bit masks per lane (member,
 //                cut, skipped) come from a v_perm LUT; two segmented scans over the
 //                lanes give every lane the members of its open segment to the left
 //                and to the right; the spans are then found bit-parallel inside the
@@ -28,6 +28,7 @@
 //                workgroups per CU.
 #include "common.hpp"
 #include "tile_common.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -77,7 +78,20 @@ struct RowsArgs {
   uint32_t *cont;                         // multi: members entering a block from the right
 };
 
-struct Chunk { uint32_t U, L, K, V, oom, oou; };
+// Per-byte bit masks of the 16*C bytes a lane owns: u32 for C = 2, u64 for C = 3, 4.
+template <int C> struct MaskOf { using T = uint64_t; };
+template <> struct MaskOf<2> { using T = uint32_t; };
+template <class M> struct Chunk { M U, L, K, V; uint32_t oom, oou; };
+
+__device__ __forceinline__ int bm_popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int bm_popc(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int bm_ctz(uint32_t x) { return __ffs(x) - 1; }                    // x != 0
+__device__ __forceinline__ int bm_ctz(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+__device__ __forceinline__ int bm_msb(uint32_t x) { return 31 - __clz(x); }                   // x != 0
+__device__ __forceinline__ int bm_msb(uint64_t x) { return 63 - __clzll((long long)x); }
+template <class M> __device__ __forceinline__ M bm_below(int n) {                              // bits [0, n), 0 <= n <= width
+  return n >= (int)(8 * sizeof(M)) ? ~(M)0 : (((M)1 << n) - (M)1);
+}
 
 // bit `bit` of the four bytes of f as a nibble
 __device__ __forceinline__ uint32_t plane_nibble(uint32_t f, int bit) {
@@ -87,25 +101,31 @@ __device__ __forceinline__ uint32_t plane_nibble(uint32_t f, int bit) {
   return t & 0xFu;
 }
 
-// The 32 bytes at g0 (32-byte aligned) of the row [rs,re): per-byte bit masks.
-__device__ __forceinline__ Chunk mhl_chunk(const uint8_t *__restrict__ xm, int64_t g0, bool live, int64_t rs, int64_t re,
-                                           const MhlLut &lut) {
-  Chunk c = {0u, 0u, 0u, 0u, 0u, 0u};
+// The 16*C bytes at g0 (16-byte aligned) of the row [rs,re): per-byte bit masks.
+template <int C>
+__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk(const uint8_t *__restrict__ xm, int64_t g0, bool live,
+                                                                   int64_t rs, int64_t re, const MhlLut &lut) {
+  using M = typename MaskOf<C>::T;
+  constexpr int W = 16 * C;
+  Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
   if (!live) return c;
   int64_t lo = rs - g0, hi = re - g0;
   if (lo < 0) lo = 0;
-  if (hi > 32) hi = 32;
+  if (hi > W) hi = W;
   if (hi <= lo) return c;
-  const uint4 w0 = *reinterpret_cast<const uint4 *>(xm + g0);
-  uint4 w1 = make_uint4(0u, 0u, 0u, 0u);
-  if (g0 + 16 < re) w1 = *reinterpret_cast<const uint4 *>(xm + g0 + 16);
-  const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-  c.V = (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-  // bytes outside the row get flag 0: byte masks of the row within each dword (only edge chunks need them)
-  const bool edge = lo > 0 || hi < 32;
-  uint32_t f8[8], kacc = 0;
+  uint32_t ww[4 * C];
 #pragma unroll
-  for (int d = 0; d < 8; d++) {
+  for (int j = 0; j < C; j++) {
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (j == 0 || g0 + 16 * j < re) w = *reinterpret_cast<const uint4 *>(xm + g0 + 16 * j);
+    ww[4 * j] = w.x; ww[4 * j + 1] = w.y; ww[4 * j + 2] = w.z; ww[4 * j + 3] = w.w;
+  }
+  c.V = bm_below<M>((int)hi) & ~bm_below<M>((int)lo);
+  // bytes outside the row get flag 0: byte masks of the row within each dword (only edge chunks need them)
+  const bool edge = lo > 0 || hi < W;
+  uint32_t f8[4 * C], kacc = 0;
+#pragma unroll
+  for (int d = 0; d < 4 * C; d++) {
     const uint32_t c4 = ww[d] & 0x0F0F0F0Fu;
     const uint32_t lo3 = c4 & 0x07070707u;
     const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
@@ -120,72 +140,68 @@ __device__ __forceinline__ Chunk mhl_chunk(const uint8_t *__restrict__ xm, int64
     }
     f8[d] = f;
     kacc |= f;
-    c.U |= plane_nibble(f, 0) << (4 * d);
-    c.L |= plane_nibble(f, 1) << (4 * d);
+    c.U |= (M)plane_nibble(f, 0) << (4 * d);
+    c.L |= (M)plane_nibble(f, 1) << (4 * d);
     c.oom = __builtin_amdgcn_sad_u8((f >> 3) & 0x01010101u, 0u, c.oom);
     c.oou = __builtin_amdgcn_sad_u8((f >> 4) & 0x01010101u, 0u, c.oou);
   }
   if (kacc & 0x04040404u) {                                   // skipped bytes are rare ('+'/'-', filler between mates)
 #pragma unroll
-    for (int d = 0; d < 8; d++) c.K |= plane_nibble(f8[d], 2) << (4 * d);
+    for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
   }
   return c;
 }
 
-__device__ __forceinline__ uint32_t lead_members(const Chunk &c) {    // members before the first cut (all if none)
-  return __popc(c.U & (c.L ? ((c.L & (0u - c.L)) - 1u) : ~0u));
+template <class M> __device__ __forceinline__ uint32_t lead_members(const Chunk<M> &c) {    // members before the first cut (all if none)
+  return (uint32_t)bm_popc(c.U & (c.L ? ((c.L & ((M)0 - c.L)) - (M)1) : ~(M)0));
 }
-__device__ __forceinline__ uint32_t trail_members(const Chunk &c) {   // members after the last cut (all if none)
-  return __popc(c.U & (c.L ? ~((2u << (31 - __clz(c.L))) - 1u) : ~0u));
+template <class M> __device__ __forceinline__ uint32_t trail_members(const Chunk<M> &c) {   // members after the last cut (all if none)
+  return (uint32_t)bm_popc(c.U & (c.L ? ~bm_below<M>(bm_msb(c.L) + 1) : ~(M)0));
 }
 
 // Span bytes of the chunk: bytes that have a member of their stretch at or before them AND at or after them
 // (segmented fills of the member bits, stopped by cuts; `enter` / `cont` = members of the open segment in the lanes
 // to the left / right).  Counted span bytes are what pass 2 adds S(M) for.
-__device__ __forceinline__ uint32_t span_bits(const Chunk &c, uint32_t enter, uint32_t cont) {
-  const uint32_t nl = ~c.L;
-  uint32_t x = c.U | ((enter > 0u && !(c.L & 1u)) ? 1u : 0u);
-  uint32_t p = nl;
-  x |= (x << 1) & p; p &= p << 1;
-  x |= (x << 2) & p; p &= p << 2;
-  x |= (x << 4) & p; p &= p << 4;
-  x |= (x << 8) & p; p &= p << 8;
-  x |= (x << 16) & p;
-  uint32_t y = c.U | ((cont > 0u && !(c.L >> 31)) ? 0x80000000u : 0u);
-  uint32_t q = nl;
-  y |= (y >> 1) & q; q &= q >> 1;
-  y |= (y >> 2) & q; q &= q >> 2;
-  y |= (y >> 4) & q; q &= q >> 4;
-  y |= (y >> 8) & q; q &= q >> 8;
-  y |= (y >> 16) & q;
+template <int W, class M>
+__device__ __forceinline__ M span_bits(const Chunk<M> &c, uint32_t enter, uint32_t cont) {
+  const M nl = ~c.L & bm_below<M>(W);
+  M x = c.U | ((enter > 0u && !(c.L & (M)1)) ? (M)1 : (M)0);
+  M p = nl;
+#pragma unroll
+  for (int sft = 1; sft < W; sft <<= 1) { x |= (x << sft) & p; p &= p << sft; }
+  M y = c.U | ((cont > 0u && !((c.L >> (W - 1)) & (M)1)) ? ((M)1 << (W - 1)) : (M)0);
+  M q = nl;
+#pragma unroll
+  for (int sft = 1; sft < W; sft <<= 1) { y |= (y >> sft) & q; q &= q >> sft; }
   return x & y & nl & ~c.K & c.V;
 }
 
-__device__ __forceinline__ uint32_t run_count(uint32_t bits) { return __popc(bits & ~(bits << 1)); }
+template <class M> __device__ __forceinline__ uint32_t run_count(M bits) { return (uint32_t)bm_popc(bits & ~(bits << 1)); }
 
 // Writes one record per run of set bits of P (stretch pieces: m from the run's segment) or Q (counted runs, m = 0).
-__device__ __forceinline__ void write_runs(uint32_t bits, bool stretch, const Chunk &c, uint32_t enter, uint32_t cont,
+template <int W, class M>
+__device__ __forceinline__ void write_runs(M bits, bool stretch, const Chunk<M> &c, uint32_t enter, uint32_t cont,
                                            uint32_t row_off0, MhlRec *__restrict__ out) {
   while (bits) {
-    const int f = __ffs(bits) - 1;
-    const uint32_t t = ~(bits >> f);
-    const int e = t ? __ffs(t) - 1 : 32 - f;                 // run length
+    const int f = bm_ctz(bits);
+    const M t = ~(bits >> f);
+    const int e = t ? bm_ctz(t) : (int)(8 * sizeof(M)) - f;    // run length
     uint32_t m = 0;
     if (stretch) {
-      const uint32_t lc = c.L & ((1u << f) - 1u);
-      const int a = lc ? 32 - __clz(lc) : 0;                  // segment = bits [a, b) between the surrounding cuts
+      const M lc = c.L & bm_below<M>(f);
+      const int a = lc ? bm_msb(lc) + 1 : 0;                   // segment = bits [a, b) between the surrounding cuts
       const int end = f + e;
-      const uint32_t hc = end < 32 ? (c.L >> end) : 0u;
-      const int b = hc ? end + __ffs(hc) - 1 : 32;
-      const uint32_t segmask = (b >= 32 ? ~0u : ((1u << b) - 1u)) & ~((1u << a) - 1u);
-      m = (a == 0 ? enter : 0u) + (uint32_t)__popc(c.U & segmask) + (b == 32 ? cont : 0u);
+      const M hc = end < W ? (c.L >> end) : (M)0;
+      const int b = hc ? end + bm_ctz(hc) : W;
+      const M segmask = bm_below<M>(b) & ~bm_below<M>(a);
+      m = (a == 0 ? enter : 0u) + (uint32_t)bm_popc(c.U & segmask) + (b == W ? cont : 0u);
     }
     MhlRec r;
     r.first = row_off0 + (uint32_t)f;
     r.last = r.first + (uint32_t)e - 1u;
     r.m = m;
     *out++ = r;
-    bits &= ~((e >= 32 ? ~0u : ((1u << e) - 1u)) << f);
+    bits &= ~(bm_below<M>(e) << f);
   }
 }
 
@@ -194,9 +210,11 @@ __device__ __forceinline__ bool mhl_keep(uint32_t h, uint32_t oo_m, uint32_t oo_
   return !((int)h < hmin || frac > max_oo);                                // :179
 }
 
-// Reads that fit one block of G x 32 bytes (every read of a short-read batch): 256/G reads per workgroup.
-template <int G>
+// Reads that fit one block of G lanes x 16*C bytes (every read of a short-read batch): 256/G reads per workgroup.
+template <int G, int C>
 __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
+  using M = typename MaskOf<C>::T;
+  constexpr int W = 16 * C;
   __shared__ uint32_t s_w[5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1);
@@ -204,10 +222,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   const bool valid = row < a.n;
   int64_t rs = 0, re = 0;
   if (valid) { rs = a.off[row]; re = a.off[row + 1]; }
-  const int64_t c0 = rs >> 5;
-  const int64_t c1 = re > rs ? (re + 31) >> 5 : c0;
-  const int64_t cidx = c0 + sub;
-  const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+  const int64_t g0 = ((rs >> 4) << 4) + (int64_t)sub * W;     // the read starts somewhere in lane 0's first 16 bytes
+  const Chunk<M> c = mhl_chunk<C>(a.xm, g0, g0 < re, rs, re, a.lut);
 
   // members of the open segment to the left (enter) and to the right (cont) of this lane
   Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   uint32_t enter = __shfl_up(pf.cnt, 1, G), cont = __shfl_down(sf.cnt, 1, G);
   if (sub == 0) enter = 0u;
   if (sub == G - 1) cont = 0u;
-  uint32_t h = __popc(c.U | c.L), oo_m = c.oom, oo_u = c.oou, anyk = c.K ? 1u : 0u;
+  uint32_t h = (uint32_t)bm_popc(c.U | c.L), oo_m = c.oom, oo_u = c.oou, anyk = c.K ? 1u : 0u;
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) {
     h += __shfl_xor(h, d, 64);
@@ -231,8 +247,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     anyk |= __shfl_xor(anyk, d, 64);
   }
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
-  const uint32_t P = keep ? span_bits(c, enter, cont) : 0u;
-  const uint32_t Q = (keep && anyk) ? (c.V & ~c.K) : 0u;
+  const M P = keep ? span_bits<W>(c, enter, cont) : (M)0;
+  const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);
 
   // record slots: exclusive scan over the workgroup, one cursor atomic per workgroup
@@ -264,10 +280,10 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     a.blkrec[row] = make_uint2(my, base == 0xFFFFFFFFu ? 0u : row_n);
   }
   if (nrec && base != 0xFFFFFFFFu) {
-    const uint32_t off0 = (uint32_t)((cidx << 5) - rs);      // row offset of the chunk's byte 0 (wraps for the first chunk)
+    const uint32_t off0 = (uint32_t)(g0 - rs);               // row offset of the chunk's byte 0 (wraps for the first chunk)
     MhlRec *out = a.recs + my;
-    write_runs(P, true, c, enter, cont, off0, out);
-    write_runs(Q, false, c, enter, cont, off0, out + run_count(P));
+    write_runs<W>(P, true, c, enter, cont, off0, out);
+    write_runs<W>(Q, false, c, enter, cont, off0, out + run_count(P));
   }
 }
 
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   uint32_t from_right = 0;
   for (int64_t b = nblk - 1; b >= 0; b--) {
     const int64_t cidx = c0 + b * 64 + lane;
-    const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    const Chunk<uint32_t> c = mhl_chunk<2>(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
     h += __popc(c.U | c.L); oo_m += c.oom; oo_u += c.oou; anyk |= c.K ? 1u : 0u;
     Seg sf = {c.L ? 1u : 0u, lead_members(c)};
 #pragma unroll
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   Seg carry = {0u, 0u};
   for (int64_t b = 0; b < nblk; b++) {
     const int64_t cidx = c0 + b * 64 + lane;
-    const Chunk c = mhl_chunk(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    const Chunk<uint32_t> c = mhl_chunk<2>(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
     Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
     carry = seg_combine(carry, last);
     const uint32_t right = __atomic_load_n(a.cont + bi + b, __ATOMIC_RELAXED);
     const uint32_t cont = exr.has ? exr.cnt : exr.cnt + right;
-    const uint32_t P = span_bits(c, enter, cont);
+    const uint32_t P = span_bits<32>(c, enter, cont);
     const uint32_t Q = anyk ? (c.V & ~c.K) : 0u;
     const uint32_t nrec = run_count(P) + run_count(Q);
     uint32_t inc = nrec;
@@ -358,8 +374,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
     if (nrec && fits) {
       const uint32_t off0 = (uint32_t)((cidx << 5) - rs);
       MhlRec *out = a.recs + (uint32_t)base + inc - nrec;
-      write_runs(P, true, c, enter, cont, off0, out);
-      write_runs(Q, false, c, enter, cont, off0, out + run_count(P));
+      write_runs<32>(P, true, c, enter, cont, off0, out);
+      write_runs<32>(Q, false, c, enter, cont, off0, out + run_count(P));
     }
   }
 }
@@ -878,15 +894,26 @@ static int pick_mhl_tile_group(int32_t max_len) {
   return g;
 }
 
-// lanes per read in k_mhl_rows (32 bytes per lane, the read may start anywhere inside its first chunk); 0 = the batch
-// has reads longer than 64 lanes cover (or EPIHIP_MHL_MULTI is set): k_mhl_rows_multi
+// k_mhl_rows variant for the batch: G lanes per read x 16*C bytes per lane, the smallest G*16*C that holds the longest
+// read wherever it starts inside its first 16 bytes; 0 = the batch has longer reads than 64 lanes cover (or
+// EPIHIP_MHL_MULTI is set): k_mhl_rows_multi.  Returned as G*8 + C.
 static int pick_mhl_group(int32_t max_len) {
   if (getenv("EPIHIP_MHL_MULTI")) return 0;
-  const int64_t chunks = ((int64_t)max_len + 31 + 31) / 32;
-  if (chunks > 64) return 0;
-  int g = 2;
-  while (g < chunks) g <<= 1;
-  return g;
+  if (const char *env = getenv("EPIHIP_MHL_GROUP")) {                      // "G,C" for A/B runs; must cover the reads
+    int g = 0, c = 0;
+    if (sscanf(env, "%d,%d", &g, &c) == 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && c >= 2 && c <= 4 &&
+        (int64_t)g * 16 * c >= (int64_t)max_len + 15)
+      return g * 8 + c;
+  }
+  int best = 0;
+  int64_t best_cap = 0;
+  for (int g = 2; g <= 64; g <<= 1)
+    for (int c = 2; c <= 4; c++) {
+      const int64_t cap = (int64_t)g * 16 * c;
+      if (cap < (int64_t)max_len + 15) continue;
+      if (!best || cap < best_cap) { best = g * 8 + c; best_cap = cap; }    // ties: the earlier (fewer lanes) wins
+    }
+  return best;
 }
 
 // nibble -> MhlLut flags for one context set (rcpp_mhl_report.cpp:104-107, :176-177, :187)
@@ -930,8 +957,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; return EPI_OK; }
 
   // pass 1 workspace: per-read info, record table, records (grown on demand like the row pool)
-  const int g = pick_mhl_group(st.max_len);
-  const bool multi = g == 0;
+  const int gc = pick_mhl_group(st.max_len);
+  const bool multi = gc == 0;
   const size_t nblkrec = multi ? (size_t)(b->nbytes >> MHL_BLK_SHIFT) + 2 * (size_t)b->n + 2 : (size_t)b->n;
   EPI_TRY(b->mhl_h.ensure((size_t)b->n * 8));
   EPI_TRY(b->mhl_blk.ensure(nblkrec * 8));
@@ -1004,9 +1031,13 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     if (multi) {
       hipLaunchKernelGGL(k_mhl_rows_multi, dim3((unsigned)((b->n + 3) / 4)), dim3(256), 0, s, ra);
     } else {
+      const int g = gc >> 3;
       const unsigned nb = (unsigned)((b->n * g + 255) / 256);
-#define EPI_LAUNCH(GG) case GG: hipLaunchKernelGGL((k_mhl_rows<GG>), dim3(nb), dim3(256), 0, s, ra); break;
-      switch (g) {
+#define EPI_LAUNCH(GG)                                                                                       \
+  case GG * 8 + 2: hipLaunchKernelGGL((k_mhl_rows<GG, 2>), dim3(nb), dim3(256), 0, s, ra); break;            \
+  case GG * 8 + 3: hipLaunchKernelGGL((k_mhl_rows<GG, 3>), dim3(nb), dim3(256), 0, s, ra); break;            \
+  case GG * 8 + 4: hipLaunchKernelGGL((k_mhl_rows<GG, 4>), dim3(nb), dim3(256), 0, s, ra); break;
+      switch (gc) {
         EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
         default: return fail(EPI_ERR_ARG, "bad group size");
       }
