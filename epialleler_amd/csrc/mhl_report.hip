@@ -36,7 +36,11 @@ namespace epi {
 
 constexpr int MHL_WG = 512;
 constexpr int MHL_T = kMhlTile;
-constexpr int MHL_NSUM = 6 * (kMhlTile + 1);      // u64 per tile: difference arrays of sum S(M), sum h, sum S(h), two strands each
+// One difference array: entry of tile position p (0..T, T = "after the tile") sits at p + p/8 -- the padding makes the
+// prefix-sum phase, where a lane walks 8 consecutive entries, free of LDS bank conflicts (stride 9 x 8 bytes per lane).
+constexpr int MHL_SLEN = (kMhlTile + 1) + ((kMhlTile + 1) >> 3) + 1;
+__host__ __device__ constexpr int mhl_pad(int p) { return p + (p >> 3); }
+constexpr int MHL_NSUM = 6 * MHL_SLEN;            // u64 per tile: difference arrays of sum S(M), sum h, sum S(h), two strands each
 constexpr int MHL_BLK_SHIFT = 11;                 // a block of the multi-block row kernel: 64 lanes x 32 bytes
 constexpr int MHL_REGIONS = 64, MHL_CUR_STRIDE = 32;   // record allocation cursors (u64 each, 256 B apart)
 
@@ -439,9 +443,9 @@ constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x
 
 struct MhlLds {
   uint32_t *cnt;                          // [2][4][T] packed code counters (as the CX kernel)
-  unsigned long long *sums;               // [3][2][T+1] difference arrays of sum S(M) (:193), sum h (:192), sum S(h) (:194)
+  unsigned long long *sums;               // [3][2][MHL_SLEN] padded difference arrays of sum S(M) (:193), sum h (:192), sum S(h) (:194)
 };
-constexpr int MHL_DN = 0, MHL_DH = 2 * (MHL_T + 1), MHL_DD = 4 * (MHL_T + 1);
+constexpr int MHL_DN = 0, MHL_DH = 2 * MHL_SLEN, MHL_DD = 4 * MHL_SLEN;
 
 struct MhlSlice {
   RowSlice rs;
@@ -516,10 +520,10 @@ __device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice 
   for (int j = 0; j < 4; j++) {
     const uint32_t fl = (f4 >> (8 * j)) & 0xFFu;
     if (!fl) continue;
-    const int p = m.sidx * (MHL_T + 1) + m.pos0 + OFF + j;
-    unsigned long long *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + p;
-    atomicAdd(d, 1ull);
-    atomicAdd(d + 1, 0ull - 1ull);
+    const int p = m.pos0 + OFF + j;
+    unsigned long long *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + m.sidx * MHL_SLEN;
+    atomicAdd(d + mhl_pad(p), 1ull);
+    atomicAdd(d + mhl_pad(p + 1), 0ull - 1ull);
   }
 }
 
@@ -535,7 +539,7 @@ __device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int su
 __device__ __forceinline__ void mhl_interval(unsigned long long *d, int64_t a, int64_t b, unsigned long long v) {
   if (a < 0) a = 0;
   if (b > MHL_T) b = MHL_T;
-  if (a < b) { atomicAdd(d + a, v); atomicAdd(d + b, 0ull - v); }
+  if (a < b) { atomicAdd(d + mhl_pad((int)a), v); atomicAdd(d + mhl_pad((int)b), 0ull - v); }
 }
 
 template <int G, int WG>
@@ -575,9 +579,9 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
     if (cur.rs.nd > 0) {
       const uint32_t h = cur.hs & 0x7FFFFFFFu;
       const unsigned long long sh = mhl_lut(h, a.H);       // S(h), :194
-      unsigned long long *dn = L.sums + MHL_DN + cur.sidx * (MHL_T + 1);
-      unsigned long long *dh = L.sums + MHL_DH + cur.sidx * (MHL_T + 1);
-      unsigned long long *dd = L.sums + MHL_DD + cur.sidx * (MHL_T + 1);
+      unsigned long long *dn = L.sums + MHL_DN + cur.sidx * MHL_SLEN;
+      unsigned long long *dh = L.sums + MHL_DH + cur.sidx * MHL_SLEN;
+      unsigned long long *dd = L.sums + MHL_DD + cur.sidx * MHL_SLEN;
       if (!(cur.hs >> 31) && sub == 0 && !(a.ablate & 4)) {   // every byte of the slice is counted: one interval per sum
         mhl_interval(dh, cur.pf, cur.pe, (unsigned long long)h);
         mhl_interval(dd, cur.pf, cur.pe, sh);
@@ -619,7 +623,8 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
   // in-place inclusive prefix sums of the six difference arrays: wavefront i takes array i (serial over a lane's
   // PER consecutive positions, one 64-lane scan of the lane totals)
   if (wave < 6) {
-    unsigned long long *arr = L.sums + wave * (T + 1) + lane * PER;
+    static_assert(PER == 8, "the padding of the difference arrays assumes 8 entries per lane");
+    unsigned long long *arr = L.sums + wave * MHL_SLEN + lane * (PER + 1);
     unsigned long long x[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) x[j] = arr[j];
@@ -669,9 +674,9 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     ok[s] = k != 0;
     key[s] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
     cov[s] = cc;                                                             // :90
-    hs[s] = L.sums[MHL_DH + s * (T + 1) + p];                                // :92 numerator
-    nu[s] = L.sums[MHL_DN + s * (T + 1) + p];                                // :93 numerator
-    de[s] = L.sums[MHL_DD + s * (T + 1) + p];                                // :93 denominator
+    hs[s] = L.sums[MHL_DH + s * MHL_SLEN + mhl_pad(p)];                      // :92 numerator
+    nu[s] = L.sums[MHL_DN + s * MHL_SLEN + mhl_pad(p)];                      // :93 numerator
+    de[s] = L.sums[MHL_DD + s * MHL_SLEN + mhl_pad(p)];                      // :93 denominator
     nr += k != 0;
   }
   uint32_t inc = (uint32_t)nr;
