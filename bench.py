@@ -28,6 +28,8 @@ WORKLOADS = {
                       "(threshold.reads=TRUE, CG)"),
     "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX",
                    desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE, report.context='CX')"),
+    "cfg3": dict(rows=100_000_000, strong=True, read_len=300, kind="cx", threshold=True, report_context="CG",
+                 desc="100M PE150 templates in total (split over the GPUs), generateCytosineReport defaults"),
     "cfg4": dict(rows=50_000_000, read_len=300, kind="mhl", desc="50M PE150 templates, generateMhlReport defaults"),
     "cfg5": dict(rows=5_000_000, read_len=10000, kind="cx", threshold=False, report_context="CG",
                  desc="5M long-read (10 kb) templates, generateCytosineReport(threshold.reads=FALSE)"),
@@ -77,6 +79,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     rows = args.rows or wl["rows"]
+    if wl.get("strong"):
+        rows = (rows + world - 1) // world                      # fixed total: BASELINE config 3 is a strong-scaling case
     L = wl["read_len"]
     n_total = rows * world
     bam = synth.generate_device(n_total=n_total, read_len=L, row_first=rank * rows, n=rows, device=local)
@@ -167,7 +171,7 @@ def main():
             "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if wl.get("strong") else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
