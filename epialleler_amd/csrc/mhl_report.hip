@@ -72,8 +72,8 @@ struct RowsArgs {
   MhlLut lut;
   int32_t hmin;
   double max_oo;
-  int32_t *rowinfo;                       // [2n]: h or -1 (dropped), 1 if the read has skipped bytes
-  uint2 *blkrec;                          // (first record, records) per row, or per 2 KiB block of a row (multi)
+  int4 *rowinfo;                          // per read: h or -1 (dropped), 1 if it has skipped bytes, (first record, records) of the read
+  uint2 *blkrec;                          // multi: (first record, records) per 2 KiB block of a read (rowinfo.z/.w unused)
   MhlRec *recs;
   uint32_t rec_cap;
   unsigned long long *rec_cursor;         // MHL_REGIONS cursors, MHL_CUR_STRIDE apart: a workgroup takes its records from region
@@ -278,11 +278,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   uint32_t row_n = nrec;
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) row_n += __shfl_xor(row_n, d, 64);
-  if (valid && sub == 0) {
-    a.rowinfo[2 * row] = keep ? (int32_t)h : -1;
-    a.rowinfo[2 * row + 1] = (int32_t)anyk;
-    a.blkrec[row] = make_uint2(my, base == 0xFFFFFFFFu ? 0u : row_n);
-  }
+  if (valid && sub == 0)
+    a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, (int32_t)my, base == 0xFFFFFFFFu ? 0 : (int32_t)row_n);
   if (nrec && base != 0xFFFFFFFFu) {
     const uint32_t off0 = (uint32_t)(g0 - rs);               // row offset of the chunk's byte 0 (wraps for the first chunk)
     MhlRec *out = a.recs + my;
@@ -328,10 +325,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
     anyk |= __shfl_xor(anyk, d, 64);
   }
   const bool keep = mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
-  if (lane == 0) {
-    a.rowinfo[2 * row] = keep ? (int32_t)h : -1;
-    a.rowinfo[2 * row + 1] = (int32_t)anyk;
-  }
+  if (lane == 0) a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, 0, 0);
   if (!keep) return;
   __threadfence();
   Seg carry = {0u, 0u};
@@ -397,7 +391,7 @@ __global__ void k_mhl_cursor_max(const unsigned long long *cur, unsigned long lo
 
 struct MhlArgs {
   RowCols c;                              // pass is always null here (no lower-casing in lMHL)
-  const int32_t *rowinfo;
+  const int4 *rowinfo;                    // see RowsArgs
   const uint2 *blkrec;
   const MhlRec *recs;
   uint32_t rec_cap;
@@ -455,21 +449,23 @@ struct MhlSlice {
   uint32_t hs;                            // haplotype size of the read | bit 31: the read has skipped bytes (its counted
                                           // runs come as records)
   int32_t rel;                            // tile position of the read's byte 0 = start - pos0
-  int32_t blk0, blk1;                     // record blocks of the read that can reach into the tile
+  int32_t blk0, blk1;                     // multi: record blocks of the read that can reach into the tile
+  uint32_t rb, rn;                        // else: the read's records
 };
 
 struct MhlRow {                           // what a lane prefetches of a candidate row
   RowVals v;
   int32_t hrow, skips;
+  uint32_t rb, rn;
 };
 
 __device__ __forceinline__ MhlRow mhl_load_row(const MhlArgs &a, const Tile &td, int r) {
   MhlRow m;
   m.v = cx_load_row(a.c, td, r);
-  m.hrow = -1; m.skips = 0;
+  m.hrow = -1; m.skips = 0; m.rb = 0; m.rn = 0;
   if (m.v.ok) {
-    const int2 ri = reinterpret_cast<const int2 *>(a.rowinfo)[r];
-    m.hrow = ri.x; m.skips = ri.y;
+    const int4 ri = a.rowinfo[r];
+    m.hrow = ri.x; m.skips = ri.y; m.rb = (uint32_t)ri.z; m.rn = (uint32_t)ri.w;
     if (m.hrow < 0) m.v.ok = false;                       // read dropped by pass 1 (:179)
   }
   return m;
@@ -479,9 +475,10 @@ template <int G>
 __device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow &row, const Tile &td, int sub, uint32_t *cnt) {
   MhlSlice m;
   m.rs = cx_slice_of<MHL_T, G, true>(a.c, row.v, td, sub, cnt);
-  m.pos0 = 0; m.pf = 0; m.pe = 0; m.sidx = 0; m.hs = 0; m.rel = 0; m.blk0 = 0; m.blk1 = -1;
+  m.pos0 = 0; m.pf = 0; m.pe = 0; m.sidx = 0; m.hs = 0; m.rel = 0; m.blk0 = 0; m.blk1 = -1; m.rb = 0; m.rn = 0;
   if (m.rs.nd > 0) {
     m.hs = (uint32_t)row.hrow | (row.skips ? 0x80000000u : 0u);
+    m.rb = row.rb; m.rn = (uint64_t)row.rb + row.rn <= a.rec_cap ? row.rn : 0u;   // pass 1 out of record space: the caller reruns
     const int32_t rel = (int32_t)((uint32_t)td.pos0 - (uint32_t)row.v.st);
     const int32_t lo = rel > 0 ? rel : 0;
     const int32_t hi = row.v.len < rel + MHL_T ? row.v.len : rel + MHL_T;
@@ -496,8 +493,6 @@ __device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow 
       const int64_t c0 = row.v.o >> 5;
       m.blk0 = (int32_t)((((row.v.o + lo) >> 5) - c0) >> 6);
       m.blk1 = (int32_t)((((row.v.o + hi - 1) >> 5) - c0) >> 6);
-    } else {
-      m.blk0 = 0; m.blk1 = 0;
     }
   }
   return m;
@@ -586,16 +581,21 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
         mhl_interval(dh, cur.pf, cur.pe, (unsigned long long)h);
         mhl_interval(dd, cur.pf, cur.pe, sh);
       }
-      const int64_t bi = a.multi ? (ocur >> MHL_BLK_SHIFT) + 2 * (int64_t)rcur : (int64_t)rcur;
-      for (int32_t blk = cur.blk0; blk <= ((a.ablate & 2) ? -1 : cur.blk1); blk++) {   // the stretch pieces (and counted runs) near the tile
-        MHL_CHECK(bi + blk >= 0 && bi + blk < a.nblkrec, 8, bi + blk, blk)
-        const uint2 br = a.blkrec[bi + blk];
-        if ((uint64_t)br.x + br.y > a.rec_cap) continue;       // pass 1 ran out of record space: the caller reruns
-        for (uint32_t k = (uint32_t)sub; k < br.y; k += G) {
-          const MhlRec rec = a.recs[br.x + k];
-          const int64_t ta = (int64_t)cur.rel + rec.first, tb = (int64_t)cur.rel + rec.last + 1;
-          if (rec.m) mhl_interval(dn, ta, tb, mhl_lut(rec.m, a.H));
-          else { mhl_interval(dh, ta, tb, (unsigned long long)h); mhl_interval(dd, ta, tb, sh); }
+      auto add_rec = [&](const MhlRec &rec) {                 // a stretch piece or a counted run that may reach into the tile
+        const int64_t ta = (int64_t)cur.rel + rec.first, tb = (int64_t)cur.rel + rec.last + 1;
+        if (rec.m) mhl_interval(dn, ta, tb, mhl_lut(rec.m, a.H));
+        else { mhl_interval(dh, ta, tb, (unsigned long long)h); mhl_interval(dd, ta, tb, sh); }
+      };
+      if (!(a.ablate & 2)) {
+        for (uint32_t k = (uint32_t)sub; k < cur.rn; k += G) add_rec(a.recs[cur.rb + k]);
+        if (a.multi) {                                         // long reads: records are kept per 2 KiB block
+          const int64_t bi = (ocur >> MHL_BLK_SHIFT) + 2 * (int64_t)rcur;
+          for (int32_t blk = cur.blk0; blk <= cur.blk1; blk++) {
+            MHL_CHECK(bi + blk >= 0 && bi + blk < a.nblkrec, 8, bi + blk, blk)
+            const uint2 br = a.blkrec[bi + blk];
+            if ((uint64_t)br.x + br.y > a.rec_cap) continue;   // pass 1 ran out of record space: the caller reruns
+            for (uint32_t k = (uint32_t)sub; k < br.y; k += G) add_rec(a.recs[br.x + k]);
+          }
         }
       }
     }
@@ -964,8 +964,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   // pass 1 workspace: per-read info, record table, records (grown on demand like the row pool)
   const int gc = pick_mhl_group(st.max_len);
   const bool multi = gc == 0;
-  const size_t nblkrec = multi ? (size_t)(b->nbytes >> MHL_BLK_SHIFT) + 2 * (size_t)b->n + 2 : (size_t)b->n;
-  EPI_TRY(b->mhl_h.ensure((size_t)b->n * 8));
+  const size_t nblkrec = multi ? (size_t)(b->nbytes >> MHL_BLK_SHIFT) + 2 * (size_t)b->n + 2 : 1;
+  EPI_TRY(b->mhl_h.ensure((size_t)b->n * 16));
   EPI_TRY(b->mhl_blk.ensure(nblkrec * 8));
   if (multi) EPI_TRY(b->mhl_cont.ensure(nblkrec * 4));
   if (b->mhl_rec_cap == 0) {
@@ -980,7 +980,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   ra.xm = b->xm; ra.off = b->off; ra.n = b->n;
   ra.lut = make_mhl_lut(ctx_mask);
   ra.hmin = (int32_t)hmin; ra.max_oo = max_ooctx_meth_frac;
-  ra.rowinfo = b->mhl_h.as<int32_t>();
+  ra.rowinfo = b->mhl_h.as<int4>();
   ra.blkrec = b->mhl_blk.as<uint2>();
   ra.rec_cursor = rec_cursor;
   ra.cont = multi ? b->mhl_cont.as<uint32_t>() : nullptr;
@@ -993,7 +993,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
 
   MhlArgs a;
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = nullptr;
-  a.rowinfo = b->mhl_h.as<int32_t>();
+  a.rowinfo = b->mhl_h.as<int4>();
   a.blkrec = b->mhl_blk.as<uint2>();
   a.multi = multi ? 1 : 0;
 #ifdef EPI_MHL_CHECK
