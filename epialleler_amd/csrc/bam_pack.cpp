@@ -24,6 +24,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include "common.hpp"
 
@@ -322,10 +323,15 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   else { memset(&opt, 0, sizeof(opt)); opt.skip_secondary = opt.skip_qcfail = opt.skip_supplementary = 1; opt.paired = -1; opt.nthreads = 1; opt.min_prob = -1; opt.highest_prob = 1; }
   if (opt.trim5 < 0 || opt.trim3 < 0) return fail(EPI_ERR_ARG, "trim must be non-negative");
 
+  const bool timing = getenv("EPIHIP_BAM_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tm0 = tnow();
+  auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[bam] %-10s %.3f s\n", what, t - tm0); tm0 = t; } };
   std::vector<uint8_t> file, bam;
   EPI_TRY(read_file(path, file));
   EPI_TRY(bgzf_inflate(file, opt.nthreads, bam));
   file.clear(); file.shrink_to_fit();
+  lap("inflate");
   if (bam.size() < 12 || memcmp(bam.data(), "BAM\1", 4) != 0) return fail(EPI_ERR_ARG, "Unable to read BAM header");
   size_t p = 8 + (size_t)rd32(bam.data() + 4);
   if (p + 4 > bam.size()) return fail(EPI_ERR_ARG, "Unable to read BAM header");
@@ -362,6 +368,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
     p += 4 + (size_t)bs;
   }
 
+  lap("index");
   // ---- .checkBam over the first 1024 records (src/rcpp_check_bam.cpp:40-50, R/internal.R:82-120) ----
   size_t nrecs = 0, npaired = 0, ntempls = 0;
   bool tXG = false, tXM = false, tYD = false, tZS = false, tMM = false;
@@ -391,16 +398,17 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   if (opt.skip_qcfail) skip_flags |= 512;
   if (opt.skip_duplicates) skip_flags |= 1024;
   if (opt.skip_supplementary) skip_flags |= 2048;
-  Packed P;
-  P.off.push_back(0);
   const int trim5 = opt.trim5, trim3 = opt.trim3;
-  if (tMM) {
+  // Each packer turns records [r_lo, r_hi) into templates appended to P; ranges are packed by several threads and
+  // concatenated in order (a paired-end range never starts inside a template).
+  auto pack_mm = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
     // ---- rcpp_read_bam_mm_single (src/rcpp_read_bam.cpp:364-579) ----
     static const char nt16_str[] = "=ACMGRSVTWYHKDBN";
     std::vector<char> seq, xm[2];
     std::vector<uint8_t> rs[2];
     std::vector<ModHit> hits;
-    for (const Rec &r : recs) {
+    for (size_t ri = r_lo; ri < r_hi; ri++) {
+      const Rec &r = recs[ri];
       if ((r.flag & skip_flags) || (int)r.mapq < opt.min_mapq) continue;                        // :423-424
       const int record_strand = (r.flag & 16) ? 1 : 0;                                          // :426
       const int32_t qw = r.l_seq < 0 ? -r.l_seq : r.l_seq;                                      // :436
@@ -467,8 +475,10 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
         P.off.push_back((int64_t)P.bytes.size());
       }
     }
-  } else if (paired) {
-    skip_flags |= 8;
+    return EPI_OK;
+  };
+  auto pack_pe = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
+    const uint16_t skip_flags_pe = skip_flags | 8;
     const uint8_t q0 = (uint8_t)(opt.min_baseq - (opt.min_baseq > 0 ? 1 : 0));   // src/rcpp_read_bam.cpp:30,57
     std::vector<uint8_t> tq(8192, q0), ts(8192, 0xFB);
     const char *tname = nullptr;
@@ -483,8 +493,9 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       std::fill(tq.begin(), tq.begin() + t_width, q0);
       std::fill(ts.begin(), ts.begin() + t_width, (uint8_t)0xFB);
     };
-    for (const Rec &r : recs) {
-      if ((r.flag & skip_flags) || !(r.flag & 0x2) || (int)r.mapq < opt.min_mapq) continue;   // :76-78
+    for (size_t ri = r_lo; ri < r_hi; ri++) {
+      const Rec &r = recs[ri];
+      if ((r.flag & skip_flags_pe) || !(r.flag & 0x2) || (int)r.mapq < opt.min_mapq) continue;   // :76-78
       bool pg, pm;
       const char *xg = aux_z(r, 'X', 'G', &pg), *xm = aux_z(r, 'X', 'M', &pm);
       if (!pg || !pm || !xg || !xm) continue;                                                   // :80-82
@@ -510,10 +521,13 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       }, &dest_end));
       if (t_width < (int)dest_end) t_width = (int)dest_end;                                     // :151
     }
-    push_template();                                                                            // :155
-  } else {
+    if (t_strand != 0) push_template();                                                         // :155 (see below for "none")
+    return EPI_OK;
+  };
+  auto pack_se = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
     std::vector<uint8_t> buf;
-    for (const Rec &r : recs) {
+    for (size_t ri = r_lo; ri < r_hi; ri++) {
+      const Rec &r = recs[ri];
       if ((r.flag & skip_flags) || (int)r.mapq < opt.min_mapq) continue;                        // :240-241
       bool pg, pm;
       const char *xg = aux_z(r, 'X', 'G', &pg), *xm = aux_z(r, 'X', 'M', &pm);
@@ -537,8 +551,50 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       if (keep > 0) P.bytes.insert(P.bytes.end(), buf.begin() + trim5, buf.begin() + trim5 + keep);
       P.off.push_back((int64_t)P.bytes.size());
     }
+    return EPI_OK;
+  };
+
+  Packed P;
+  P.off.push_back(0);
+  {
+    size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
+    if (recs.size() < 1024) K = 1;
+    std::vector<size_t> cut(K + 1);
+    for (size_t k = 0; k <= K; k++) {
+      size_t c = recs.size() * k / K;
+      if (!tMM && paired)                                   // a template's records are neighbours with one QNAME
+        while (c > 0 && c < recs.size() && strcmp(recs[c].qname, recs[c - 1].qname) == 0) c++;
+      cut[k] = c;
+    }
+    std::vector<Packed> part(K);
+    std::vector<int> rcs(K, EPI_OK);
+    std::vector<std::string> msgs(K);
+    auto run = [&](size_t k) {
+      part[k].off.push_back(0);
+      rcs[k] = tMM ? pack_mm(cut[k], cut[k + 1], part[k]) : paired ? pack_pe(cut[k], cut[k + 1], part[k]) : pack_se(cut[k], cut[k + 1], part[k]);
+      if (rcs[k] != EPI_OK) msgs[k] = epi_last_error();     // the message is thread-local
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < K; k++) th.emplace_back(run, k);
+    run(0);
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < K; k++)
+      if (rcs[k] != EPI_OK) return fail(rcs[k], "%s", msgs[k].c_str());
+    for (size_t k = 0; k < K; k++) {
+      const Packed &q = part[k];
+      const int64_t shift = (int64_t)P.bytes.size();
+      P.rname.insert(P.rname.end(), q.rname.begin(), q.rname.end());
+      P.strand.insert(P.strand.end(), q.strand.begin(), q.strand.end());
+      P.start.insert(P.start.end(), q.start.begin(), q.start.end());
+      for (size_t i = 1; i < q.off.size(); i++) P.off.push_back(q.off[i] + shift);
+      P.bytes.insert(P.bytes.end(), q.bytes.begin(), q.bytes.end());
+    }
+    if (!tMM && paired && P.rname.empty()) {                // the reference pushes its (never opened) template all the same, :155
+      P.rname.push_back(1); P.strand.push_back(0); P.start.push_back(trim5 + 1); P.off.push_back(0);
+    }
   }
 
+  lap("pack");
   // ---- templid := 0..N-1 ; setorder(rname, start) -- stable (R/internal.R:193-195) ----
   const size_t n = P.rname.size();
   std::vector<uint32_t> order(n);
@@ -573,6 +629,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   }
   out->off[n] = w;
   memset(out->xm + w, 0xFB, cap - (size_t)w);
+  lap("sort+copy");
   out->n = (int64_t)n;
   out->nbytes = w;
   out->xm_capacity = (int64_t)cap;

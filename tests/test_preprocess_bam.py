@@ -29,6 +29,9 @@ def ea():
     ("dragen-se-unsort-xg-xm.bam", dict(trim=1)),
     ("dragen-se-unsort-xg-xm.bam", dict(min_baseq=30)),
     ("dragen-pe-namesort-xg-xm.bam", {}),
+    ("capture.bam", dict(nthreads=7)),                   # paired-end ranges packed by several threads
+    ("amplicon010meth.bam", dict(nthreads=3)),
+    ("dragen-se-unsort-xg-xm.bam", dict(nthreads=5)),
 ])
 def test_packer_matches_oracle(ea, name, kw):
     b = ea.preprocessBam(os.path.join(BAM, name), **kw)
