@@ -80,6 +80,7 @@ struct RowsArgs {
                                           // blockIdx % MHL_REGIONS (one cursor for all serialises 3 M atomics: 25 ms); a cursor
                                           // may run past its region's capacity rec_cap / MHL_REGIONS: the caller regrows and reruns
   uint32_t *cont;                         // multi: members entering a block from the right
+  uint32_t *max_h;                        // largest haplotype size among the kept reads (sizes the LDS sums of pass 2)
 };
 
 // Per-byte bit masks of the 16*C bytes a lane owns: u32 for C = 2, u64 for C = 3, 4.
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     anyk |= __shfl_xor(anyk, d, 64);
   }
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
+  if (keep && sub == 0 && h > __atomic_load_n(a.max_h, __ATOMIC_RELAXED)) atomicMax(a.max_h, h);   // rarely taken after the first waves
   const M P = keep ? span_bits<W>(c, enter, cont) : (M)0;
   const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   }
   const bool keep = mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   if (lane == 0) a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, 0, 0);
+  if (keep && lane == 0 && h > __atomic_load_n(a.max_h, __ATOMIC_RELAXED)) atomicMax(a.max_h, h);
   if (!keep) return;
   __threadfence();
   Seg carry = {0u, 0u};
@@ -435,10 +438,15 @@ struct MhlArgs {
 //   flag:  0 0 0 2 4 0 0 0 | 8 0  0  0 |  0
 constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x00000008u, kFlagHi1 = 0x00000000u;
 
-struct MhlLds {
+// ST = type of the LDS difference arrays: u64, or u32 when no tile (or heavy-tile chunk) of the batch can reach 2^31 in
+// any of the three sums -- decided on the host from the largest haplotype size pass 1 saw; u32 entries wrap like signed
+// numbers and are sign-extended where they leave LDS for the u64 slabs.
+template <class ST> struct MhlLds {
   uint32_t *cnt;                          // [2][4][T] packed code counters (as the CX kernel)
-  unsigned long long *sums;               // [3][2][MHL_SLEN] padded difference arrays of sum S(M) (:193), sum h (:192), sum S(h) (:194)
+  ST *sums;                               // [3][2][MHL_SLEN] padded difference arrays of sum S(M) (:193), sum h (:192), sum S(h) (:194)
 };
+__device__ __forceinline__ unsigned long long mhl_widen(unsigned long long v) { return v; }
+__device__ __forceinline__ unsigned long long mhl_widen(uint32_t v) { return (unsigned long long)(long long)(int32_t)v; }
 constexpr int MHL_DN = 0, MHL_DH = 2 * MHL_SLEN, MHL_DD = 4 * MHL_SLEN;
 
 struct MhlSlice {
@@ -500,8 +508,8 @@ __device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow 
 
 // One dword of a row: the packed CX counters; stray nibbles 3/4/8 additionally bump one of the three sums at their
 // position (+1 there, -1 after it, in the difference arrays).
-template <int OFF, bool FIRST>
-__device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice &m, const MhlLds &L) {
+template <int OFF, bool FIRST, class ST>
+__device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice &m, const MhlLds<ST> &L) {
   cx_add_dword<MHL_T, OFF, FIRST, true>(w, k, m.rs);
   const uint32_t c4 = w & 0x0F0F0F0Fu;
   const uint32_t lo3 = c4 & 0x07070707u;
@@ -516,14 +524,14 @@ __device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice 
     const uint32_t fl = (f4 >> (8 * j)) & 0xFFu;
     if (!fl) continue;
     const int p = m.pos0 + OFF + j;
-    unsigned long long *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + m.sidx * MHL_SLEN;
-    atomicAdd(d + mhl_pad(p), 1ull);
-    atomicAdd(d + mhl_pad(p + 1), 0ull - 1ull);
+    ST *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + m.sidx * MHL_SLEN;
+    atomicAdd(d + mhl_pad(p), (ST)1);
+    atomicAdd(d + mhl_pad(p + 1), (ST)0 - (ST)1);
   }
 }
 
-template <int G, int U0, int U1>
-__device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int sub, const MhlSlice &cur, const MhlLds &L) {
+template <int G, int U0, int U1, class ST>
+__device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int sub, const MhlSlice &cur, const MhlLds<ST> &L) {
   if constexpr (U0 < U1) {
     if (sub + U0 * G < cur.rs.nd) mhl_add_dword<4 * G * U0, U0 == 0>(w[U0], sub + U0 * G, cur, L);
     mhl_add_range<G, U0 + 1, U1>(w, sub, cur, L);
@@ -531,14 +539,15 @@ __device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int su
 }
 
 // +v on tile positions [a, b) of one difference array
-__device__ __forceinline__ void mhl_interval(unsigned long long *d, int64_t a, int64_t b, unsigned long long v) {
+template <class ST>
+__device__ __forceinline__ void mhl_interval(ST *d, int64_t a, int64_t b, unsigned long long v) {
   if (a < 0) a = 0;
   if (b > MHL_T) b = MHL_T;
-  if (a < b) { atomicAdd(d + mhl_pad((int)a), v); atomicAdd(d + mhl_pad((int)b), 0ull - v); }
+  if (a < b) { atomicAdd(d + mhl_pad((int)a), (ST)v); atomicAdd(d + mhl_pad((int)b), (ST)0 - (ST)v); }
 }
 
-template <int G, int WG>
-__device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td, const MhlLds &L) {
+template <int G, int WG, class ST>
+__device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td, const MhlLds<ST> &L) {
   constexpr int R = 64 / G;
   constexpr int NW = WG / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -574,9 +583,9 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
     if (cur.rs.nd > 0) {
       const uint32_t h = cur.hs & 0x7FFFFFFFu;
       const unsigned long long sh = mhl_lut(h, a.H);       // S(h), :194
-      unsigned long long *dn = L.sums + MHL_DN + cur.sidx * MHL_SLEN;
-      unsigned long long *dh = L.sums + MHL_DH + cur.sidx * MHL_SLEN;
-      unsigned long long *dd = L.sums + MHL_DD + cur.sidx * MHL_SLEN;
+      ST *dn = L.sums + MHL_DN + cur.sidx * MHL_SLEN;
+      ST *dh = L.sums + MHL_DH + cur.sidx * MHL_SLEN;
+      ST *dd = L.sums + MHL_DD + cur.sidx * MHL_SLEN;
       if (!(cur.hs >> 31) && sub == 0 && !(a.ablate & 4)) {   // every byte of the slice is counted: one interval per sum
         mhl_interval(dh, cur.pf, cur.pe, (unsigned long long)h);
         mhl_interval(dd, cur.pf, cur.pe, sh);
@@ -612,8 +621,13 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
 
 // Rule, prefix sums of the difference arrays, ordered compaction of one tile (one position per thread).  The pool rows
 // carry the three integer sums; the two divisions (:92-93) are done by k_mhl_gather, one row per lane.
-template <int WG, bool PK>
-__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds &L, uint32_t *s_scan) {
+__device__ __forceinline__ uint32_t mhl_shfl_up(uint32_t v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ unsigned long long mhl_shfl_up(unsigned long long v, int d) {
+  return ((unsigned long long)__shfl_up((uint32_t)(v >> 32), d, 64) << 32) | __shfl_up((uint32_t)v, d, 64);
+}
+
+template <int WG, bool PK, class ST>
+__device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds<ST> &L, uint32_t *s_scan) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   constexpr int PER = T / 64;                             // positions per lane in the prefix-sum phase
@@ -624,20 +638,19 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
   // PER consecutive positions, one 64-lane scan of the lane totals)
   if (wave < 6) {
     static_assert(PER == 8, "the padding of the difference arrays assumes 8 entries per lane");
-    unsigned long long *arr = L.sums + wave * MHL_SLEN + lane * (PER + 1);
-    unsigned long long x[PER];
+    ST *arr = L.sums + wave * MHL_SLEN + lane * (PER + 1);
+    ST x[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) x[j] = arr[j];
 #pragma unroll
     for (int j = 1; j < PER; j++) x[j] += x[j - 1];
-    unsigned long long inc = x[PER - 1];
+    ST inc = x[PER - 1];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t lo = __shfl_up((uint32_t)inc, d, 64);
-      const uint32_t hi = __shfl_up((uint32_t)(inc >> 32), d, 64);
-      if (lane >= d) inc += ((unsigned long long)hi << 32) | lo;
+      const ST t = mhl_shfl_up(inc, d);
+      if (lane >= d) inc += t;
     }
-    const unsigned long long ex = inc - x[PER - 1];
+    const ST ex = inc - x[PER - 1];
 #pragma unroll
     for (int j = 0; j < PER; j++) arr[j] = x[j] + ex;
   }
@@ -717,22 +730,32 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
 
 constexpr int MHL_LDS_CNT = cx_lds_dwords<MHL_T, true>() + 2 * kCxGuard;
 
-__device__ __forceinline__ MhlLds mhl_lds(uint32_t *cnt, unsigned long long *sums) {
-  MhlLds L;
+template <class ST>
+__device__ __forceinline__ MhlLds<ST> mhl_lds(uint32_t *cnt, ST *sums) {
+  MhlLds<ST> L;
   L.cnt = cnt;
   L.sums = sums;
   return L;
 }
 
-// three workgroups per CU (41 KiB of LDS each): 6 waves per SIMD
-template <int G, int WG>
-__global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
+// three workgroups per CU (6 waves per SIMD, 80 VGPRs) for both sum types: with u32 sums (30 KiB of LDS) a fourth would
+// fit, but at 64 VGPRs the kernel spills 33 of them and runs 26 ms instead of 13.7 on config 4 (u64: 17.5)
+template <class ST> constexpr int mhl_waves_per_simd() { return 6; }
+
+// adds a tile's LDS difference arrays to its u64 slab in HBM
+template <int WG, class ST>
+__device__ __forceinline__ void mhl_dump_sums(const ST *sums, unsigned long long *ds) {
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const ST v = sums[i]; if (v) atomicAdd(ds + i, mhl_widen(v)); }
+}
+
+template <int G, int WG, class ST>
+__global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_tiles(MhlArgs a, int ntiles) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
-  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  __shared__ __attribute__((aligned(16))) ST sums[MHL_NSUM];
   __shared__ uint32_t s_scan[NW + 2];
-  const MhlLds L = mhl_lds(cnt_raw + kCxGuard, sums);
+  const MhlLds<ST> L = mhl_lds(cnt_raw + kCxGuard, sums);
   const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
@@ -748,14 +771,13 @@ __global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
     return;
   }
   for (int i = threadIdx.x; i < MHL_LDS_CNT; i += WG) cnt_raw[i] = 0;
-  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = (ST)0;
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
   if (td.slot >= 0) {                                    // shared with another rank: hand the raw sums over
     cx_dump_slab<T, WG, true>(L.cnt, reinterpret_cast<int32_t *>(a.shared_cnt + (int64_t)td.slot * (16 * T)));
-    unsigned long long *ds = a.shared_sums + (int64_t)td.slot * MHL_NSUM;
-    for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
+    mhl_dump_sums<WG>(sums, a.shared_sums + (int64_t)td.slot * MHL_NSUM);
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
@@ -764,12 +786,12 @@ __global__ __launch_bounds__(WG, 6) void k_mhl_tiles(MhlArgs a, int ntiles) {
 }
 
 // One chunk of the candidate rows of one heavy tile -> added into that tile's slab in HBM.
-template <int G, int WG>
-__global__ __launch_bounds__(WG, 6) void k_mhl_heavy(MhlArgs a) {
+template <int G, int WG, class ST>
+__global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_heavy(MhlArgs a) {
   constexpr int T = MHL_T;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
-  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
-  const MhlLds L = mhl_lds(cnt_raw + kCxGuard, sums);
+  __shared__ __attribute__((aligned(16))) ST sums[MHL_NSUM];
+  const MhlLds<ST> L = mhl_lds(cnt_raw + kCxGuard, sums);
   const int tile = (int)a.heavy_list[blockIdx.y];
   Tile td = a.tiles[tile];
   const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
@@ -777,14 +799,14 @@ __global__ __launch_bounds__(WG, 6) void k_mhl_heavy(MhlArgs a) {
   td.row_lo = lo;
   if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
   for (int i = threadIdx.x; i < MHL_LDS_CNT; i += WG) cnt_raw[i] = 0;
-  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = 0ull;
+  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = (ST)0;
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
   uint32_t *dc = td.slot >= 0 ? a.shared_cnt + (int64_t)td.slot * (16 * T) : a.heavy_cnt + (int64_t)blockIdx.y * (16 * T);
   unsigned long long *ds = td.slot >= 0 ? a.shared_sums + (int64_t)td.slot * MHL_NSUM : a.heavy_sums + (int64_t)blockIdx.y * MHL_NSUM;
   cx_dump_slab<T, WG, true>(L.cnt, reinterpret_cast<int32_t *>(dc));
-  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) { const unsigned long long v = sums[i]; if (v) atomicAdd(ds + i, v); }
+  mhl_dump_sums<WG>(sums, ds);
 }
 
 // Rule + rows of one tile whose sums sit in HBM slabs (u32 counters [16][T] + MHL_NSUM u64): heavy and shared tiles.
@@ -793,7 +815,7 @@ __device__ __forceinline__ void mhl_emit_from_slab(const MhlArgs &a, int tile, c
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt[16 * T];
-  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];
+  __shared__ __attribute__((aligned(16))) unsigned long long sums[MHL_NSUM];   // the slabs are always u64
   __shared__ uint32_t s_scan[NW + 2];
   for (int i = threadIdx.x; i < 16 * T; i += WG) cnt[i] = sc[i];
   for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = ss[i];
@@ -867,23 +889,25 @@ static int ensure_mhl_pool(epi_batch *b, size_t rows) {
   return EPI_OK;
 }
 
+template <class ST>
 static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
   const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_mhl_tiles<8, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_mhl_tiles<16, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_mhl_tiles<32, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_mhl_tiles<64, MHL_WG>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 8: hipLaunchKernelGGL((k_mhl_tiles<8, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_mhl_tiles<16, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_mhl_tiles<32, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_mhl_tiles<64, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
   }
 }
 
+template <class ST>
 static void launch_mhl_heavy(int g, uint32_t nheavy, uint32_t nchunks, hipStream_t s, const MhlArgs &a) {
   const dim3 grid(nchunks, nheavy);
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_mhl_heavy<8, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_mhl_heavy<16, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_mhl_heavy<32, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_mhl_heavy<64, MHL_WG>), grid, dim3(MHL_WG), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_mhl_heavy<8, MHL_WG, ST>), grid, dim3(MHL_WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_mhl_heavy<16, MHL_WG, ST>), grid, dim3(MHL_WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_mhl_heavy<32, MHL_WG, ST>), grid, dim3(MHL_WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_mhl_heavy<64, MHL_WG, ST>), grid, dim3(MHL_WG), 0, s, a); break;
   }
   hipLaunchKernelGGL((k_mhl_emit_heavy<MHL_WG>), dim3(nheavy), dim3(MHL_WG), 0, s, a);
 }
@@ -984,6 +1008,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   ra.blkrec = b->mhl_blk.as<uint2>();
   ra.rec_cursor = rec_cursor;
   ra.cont = multi ? b->mhl_cont.as<uint32_t>() : nullptr;
+  ra.max_h = b->misc.as<uint32_t>() + 14;                    // misc[14]
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
@@ -1012,6 +1037,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.heavy_rows = 16384;
   if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
   if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // packed u16 counters: a base adds at most 2
+  const int heavy_rows_base = a.heavy_rows;
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
   a.heavy_list = b->heavy_list.as<uint32_t>();
@@ -1032,6 +1058,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     ra.recs = b->mhl_m.as<MhlRec>();
     ra.rec_cap = (uint32_t)b->mhl_rec_cap;
     EPI_HIP(hipMemsetAsync(rec_cursor, 0, (size_t)MHL_REGIONS * MHL_CUR_STRIDE * 8, s));
+    EPI_HIP(hipMemsetAsync(ra.max_h, 0, 4, s));
     prof_begin("mhl_rows", s);
     if (multi) {
       hipLaunchKernelGGL(k_mhl_rows_multi, dim3((unsigned)((b->n + 3) / 4)), dim3(256), 0, s, ra);
@@ -1051,6 +1078,28 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     prof_end("mhl_rows", s);
     hipLaunchKernelGGL(k_mhl_cursor_max, dim3(1), dim3(MHL_REGIONS), 0, s, rec_cursor, rec_max);
     EPI_HIP(hipGetLastError());
+    uint32_t p1[3];                                        // {fullest record region (u64), largest haplotype size}
+    EPI_TRY(read_scalars(b, s, rec_max, 12, p1));
+    const unsigned long long rec_used = ((unsigned long long)p1[1] << 32) | p1[0];
+    if (rec_used > b->mhl_rec_cap / MHL_REGIONS) {         // record space ran out: the need is known now, redo pass 1
+      if (attempt == 2) return fail(EPI_ERR_STATE, "stretch record overflow after regrow");
+      const unsigned long long want = (rec_used + rec_used / 16 + 64) * MHL_REGIONS;
+      if (want > 0xFFFFFFF0ull) return fail(EPI_ERR_NOMEM, "too many methylated stretches in one batch (%llu)", want);
+      b->mhl_rec_cap = (size_t)want;
+      EPI_TRY(b->mhl_m.ensure(b->mhl_rec_cap * sizeof(MhlRec)));
+      continue;
+    }
+    // u32 LDS sums if no position of a tile (or heavy-tile chunk) can reach 2^31: rows x (the largest value a read
+    // can add: S(h) >= h, S(M) <= S(h) for M <= h; + 1 for a stray nibble at the position)
+    uint32_t hcap = p1[2] > 65535u ? 65535u : p1[2];
+    if (hcap >= H) hcap = H;
+    const unsigned long long vmax = nrS(hcap) > 1 ? nrS(hcap) : 1;
+    const unsigned long long narrow_rows = ((1ull << 31) - 1) / (vmax + 1);
+    bool narrow = narrow_rows >= 512;
+    if (const char *env = getenv("EPIHIP_MHL_SUMS")) narrow = narrow && atoi(env) == 32;   // "64" forces the wide kernel
+    a.heavy_rows = heavy_rows_base;
+    if (narrow && (unsigned long long)a.heavy_rows > narrow_rows) a.heavy_rows = (int)narrow_rows;
+    a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
 
     // pass 2
     a.recs = ra.recs;
@@ -1064,7 +1113,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
     EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     prof_begin("mhl_tiles", s);
-    launch_mhl_tiles(tg, nt, s, a);
+    if (narrow) launch_mhl_tiles<uint32_t>(tg, nt, s, a); else launch_mhl_tiles<unsigned long long>(tg, nt, s, a);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -1076,21 +1125,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
                             (int)d[1], (int)d[2], d[3], d[4], (long long)b->n, nt, attempt);
     }
 #endif
-    uint32_t host[13];
-    EPI_TRY(read_scalars(b, s, cursor, 52, host));         // misc[1..13]
-    const unsigned long long rec_used = ((unsigned long long)host[12] << 32) | host[11];   // fullest region
-    if (rec_used > b->mhl_rec_cap / MHL_REGIONS) {         // record space ran out: the need is known now
-      if (attempt == 2) return fail(EPI_ERR_STATE, "stretch record overflow after regrow");
-      const unsigned long long want = (rec_used + rec_used / 16 + 64) * MHL_REGIONS;
-      if (want > 0xFFFFFFF0ull) return fail(EPI_ERR_NOMEM, "too many methylated stretches in one batch (%llu)", want);
-      b->mhl_rec_cap = (size_t)want;
-      EPI_TRY(b->mhl_m.ensure(b->mhl_rec_cap * sizeof(MhlRec)));
-      if (nshared > 0) {
-        EPI_HIP(hipMemsetAsync(a.shared_cnt, 0, (size_t)nshared * 16 * MHL_T * 4, s));
-        EPI_HIP(hipMemsetAsync(a.shared_sums, 0, (size_t)nshared * MHL_NSUM * 8, s));
-      }
-      continue;
-    }
+    uint32_t host[8];
+    EPI_TRY(read_scalars(b, s, cursor, 32, host));         // misc[1..8]
     if (host[2] > 0) {                                     // pile-ups: split, reduce in HBM, emit, rescan
       const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
       EPI_TRY(b->heavy_slab.ensure((size_t)nheavy * 16 * MHL_T * 4));
@@ -1100,7 +1136,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
       EPI_HIP(hipMemsetAsync(a.heavy_cnt, 0, (size_t)nheavy * 16 * MHL_T * 4, s));
       EPI_HIP(hipMemsetAsync(a.heavy_sums, 0, (size_t)nheavy * MHL_NSUM * 8, s));
       prof_begin("mhl_heavy", s);
-      launch_mhl_heavy(tg, nheavy, nchunks, s, a);
+      if (narrow) launch_mhl_heavy<uint32_t>(tg, nheavy, nchunks, s, a); else launch_mhl_heavy<unsigned long long>(tg, nheavy, nchunks, s, a);
       prof_end("mhl_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
