@@ -211,6 +211,21 @@ def test_heavy_tiles_are_split(ea, monkeypatch):
     check_all(ea, H.bam("amplicon010meth.bam"), mhl=True, contexts=("CG",))
 
 
+def test_lmhl_sum_width_and_lowered_heavy_threshold(ea):
+    """lMHL pass 2 keeps its sums in u32 LDS arrays when rows x S(largest h) stays below 2^31; deep tiles are then split
+    earlier (heavy path) so that this holds for every chunk.  Haplotypes of ~100 sites on 6000-deep pile-ups sit exactly
+    in that regime; ~250 sites push the same data to the u64 kernel."""
+    rng = np.random.default_rng(41)
+    for max_len, alphabet in ((300, "zZ."), (300, "zzZ"), (700, "zZ")):
+        t = synth_np.random_templates(rng, 6000, max_len - 50, max_len, 2, 80, alphabet=alphabet)
+        bam = pb(ea, t)
+        for hmax in (0, 7):
+            got = ea.rcpp_mhl_report(bam, "Zz", hmax, 0, 1.0)
+            want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, 0, 1.0)
+            H.assert_reports_equal(dict(got), want, float_cols=("length", "lmhl"))
+        bam.close()
+
+
 def test_long_reads(ea):
     rng = np.random.default_rng(29)
     t = synth_np.random_templates(rng, 40, 5000, 12000, 2, 30000, alphabet="......hhxzzZZZHXuU-")
