@@ -138,9 +138,15 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off,
                      const int32_t *rname, const int32_t *strand, const int32_t *start,
                      int64_t n, epi_batch **out);
 
-/* Zero-copy: the caller (e.g. a torch tensor) owns the device buffers and
- * keeps them alive.  d_xm must be 16-byte aligned and xm_capacity (bytes
- * allocated) >= off[n] rounded up to 16.  nbytes = off[n]. */
+/* Zero-copy: the caller (e.g. a torch tensor) owns the device buffers, keeps
+ * them alive and does not change them while the batch exists.  d_xm must be
+ * 16-byte aligned and xm_capacity (bytes allocated) >= off[n] rounded up to
+ * 16.  nbytes = off[n].
+ * Both constructors queue, on the HIP null stream, one pass over the columns
+ * (longest read, (rname,start) order, strand and offset validity): the data
+ * must be complete as seen from that stream.  Its verdict is raised by the
+ * first report call (EPI_ERR_UNSORTED / EPI_ERR_ARG); per-read functions
+ * accept unsorted rows. */
 int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int64_t nbytes,
                     const int64_t *d_off, const int32_t *d_rname, const int32_t *d_strand,
                     const int32_t *d_start, int64_t n, epi_batch **out);
