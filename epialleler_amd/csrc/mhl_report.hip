@@ -81,6 +81,7 @@ struct RowsArgs {
                                           // may run past its region's capacity rec_cap / MHL_REGIONS: the caller regrows and reruns
   uint32_t *cont;                         // multi: members entering a block from the right
   uint32_t *max_h;                        // largest haplotype size among the kept reads (sizes the LDS sums of pass 2)
+  int ablate;                             // timing experiments only (EPIHIP_MHL_ABLATE >> 8)
 };
 
 // Per-byte bit masks of the 16*C bytes a lane owns: u32 for C = 2, u64 for C = 3, 4.
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   }
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   if (keep && sub == 0 && h > __atomic_load_n(a.max_h, __ATOMIC_RELAXED)) atomicMax(a.max_h, h);   // rarely taken after the first waves
-  const M P = keep ? span_bits<W>(c, enter, cont) : (M)0;
+  const M P = (keep && !(a.ablate & 4)) ? span_bits<W>(c, enter, cont) : (M)0;
   const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     for (int w = 0; w < 4; w++) { const uint32_t t = s_w[w]; s_w[w] = acc; acc += t; }
     const uint32_t region = blockIdx.x & (MHL_REGIONS - 1), region_cap = a.rec_cap / MHL_REGIONS;
     unsigned long long base = 0;
-    if (acc) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)acc);
+    if (acc && !(a.ablate & 1)) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)acc);
     s_w[4] = (base + acc <= (unsigned long long)region_cap) ? region * region_cap + (uint32_t)base : 0xFFFFFFFFu;   // does not fit: count only
   }
   __syncthreads();
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   for (int d = G / 2; d >= 1; d >>= 1) row_n += __shfl_xor(row_n, d, 64);
   if (valid && sub == 0)
     a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, (int32_t)my, base == 0xFFFFFFFFu ? 0 : (int32_t)row_n);
-  if (nrec && base != 0xFFFFFFFFu) {
+  if (nrec && base != 0xFFFFFFFFu && !(a.ablate & 2)) {
     const uint32_t off0 = (uint32_t)(g0 - rs);               // row offset of the chunk's byte 0 (wraps for the first chunk)
     MhlRec *out = a.recs + my;
     write_runs<W>(P, true, c, enter, cont, off0, out);
@@ -1009,6 +1010,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   ra.rec_cursor = rec_cursor;
   ra.cont = multi ? b->mhl_cont.as<uint32_t>() : nullptr;
   ra.max_h = b->misc.as<uint32_t>() + 14;                    // misc[14]
+  ra.ablate = 0;
+  if (const char *env = getenv("EPIHIP_MHL_ABLATE")) ra.ablate = atoi(env) >> 8;
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
