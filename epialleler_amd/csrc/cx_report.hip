@@ -450,7 +450,9 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
-  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * (T / 4) + 65536));
+  // first call on this batch: room for a typical density of reported cytosines (CpG ~7 % of (pos,strand) pairs, all
+  // contexts ~50 %); an overflow is detected below and costs one rerun with the exact size
+  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * ((ctx_mask & ~(1u << 7)) ? (5 * T) / 4 : T / 4) + 65536));
   const int grp = pick_cx_group(st.max_len, T);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
