@@ -43,6 +43,13 @@ __host__ __device__ constexpr int mhl_pad(int p) { return p + (p >> 3); }
 constexpr int MHL_NSUM = 6 * MHL_SLEN;            // u64 per tile: difference arrays of sum S(M), sum h, sum S(h), two strands each
 constexpr int MHL_BLK_SHIFT = 11;                 // a block of the multi-block row kernel: 64 lanes x 32 bytes
 constexpr int MHL_REGIONS = 64, MHL_CUR_STRIDE = 32;   // record allocation cursors (u64 each, 256 B apart)
+#ifndef EPI_MHL_NU
+#define EPI_MHL_NU CX_NU
+#endif
+constexpr int MHL_NU = EPI_MHL_NU;                // dword loads a lane keeps in flight per row in the tile kernel
+#ifndef EPI_MHL_WPS
+#define EPI_MHL_WPS 6
+#endif
 
 __host__ __device__ __forceinline__ uint64_t nrS(uint64_t n) { return n < 2 ? n : (n * (n + 1) * (n + 2)) / 6; }   // :39-43
 // mhl_lookup[n] (:110-116) without the table; indices clamp at 65535 (the reference's table ends there)
@@ -532,7 +539,7 @@ __device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice 
 }
 
 template <int G, int U0, int U1, class ST>
-__device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[CX_NU], int sub, const MhlSlice &cur, const MhlLds<ST> &L) {
+__device__ __forceinline__ void mhl_add_range(const uint32_t (&w)[MHL_NU], int sub, const MhlSlice &cur, const MhlLds<ST> &L) {
   if constexpr (U0 < U1) {
     if (sub + U0 * G < cur.rs.nd) mhl_add_dword<4 * G * U0, U0 == 0>(w[U0], sub + U0 * G, cur, L);
     mhl_add_range<G, U0 + 1, U1>(w, sub, cur, L);
@@ -573,9 +580,9 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
       }
 #endif
     }
-    uint32_t w[CX_NU];
+    uint32_t w[MHL_NU];
 #pragma unroll
-    for (int u = 0; u < CX_NU; u++) w[u] = sub + u * G < cur.rs.nd ? cur.rs.src[u * G] : 0u;
+    for (int u = 0; u < MHL_NU; u++) w[u] = sub + u * G < cur.rs.nd ? cur.rs.src[u * G] : 0u;
     const int rcur = r;
     const int64_t ocur = row.v.o;
 
@@ -609,8 +616,8 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
         }
       }
     }
-    if (!(a.ablate & 8)) mhl_add_range<G, 0, CX_NU>(w, sub, cur, L);
-    for (int k = sub + CX_NU * G; k < cur.rs.nd; k += G) {
+    if (!(a.ablate & 8)) mhl_add_range<G, 0, MHL_NU>(w, sub, cur, L);
+    for (int k = sub + MHL_NU * G; k < cur.rs.nd; k += G) {
       MhlSlice t = cur;
 #pragma unroll
       for (int j = 0; j < 4; j++) t.rs.dst[j] = cur.rs.dst[j] + 4 * (k - sub);
@@ -741,7 +748,7 @@ __device__ __forceinline__ MhlLds<ST> mhl_lds(uint32_t *cnt, ST *sums) {
 
 // three workgroups per CU (6 waves per SIMD, 80 VGPRs) for both sum types: with u32 sums (30 KiB of LDS) a fourth would
 // fit, but at 64 VGPRs the kernel spills 33 of them and runs 26 ms instead of 13.7 on config 4 (u64: 17.5)
-template <class ST> constexpr int mhl_waves_per_simd() { return 6; }
+template <class ST> constexpr int mhl_waves_per_simd() { return sizeof(ST) == 4 ? EPI_MHL_WPS : 6; }
 
 // adds a tile's LDS difference arrays to its u64 slab in HBM
 template <int WG, class ST>
@@ -920,7 +927,7 @@ static int pick_mhl_tile_group(int32_t max_len) {
   const int slice = (max_len < MHL_T ? max_len : MHL_T) + 3;
   const int nd = (slice + 3) / 4;
   int g = 8;
-  while (g < 64 && g * CX_NU < nd) g <<= 1;
+  while (g < 64 && g * MHL_NU < nd) g <<= 1;
   return g;
 }
 
