@@ -51,6 +51,12 @@ class MhlTable(C.Structure):
                [("length", C.POINTER(C.c_double)), ("lmhl", C.POINTER(C.c_double))]
 
 
+class PatternTable(C.Structure):
+    _fields_ = [("npat", C.c_int64), ("ncol", C.c_int32), ("positions", C.POINTER(C.c_int32))] + \
+               [(k, C.POINTER(C.c_int32)) for k in ("strand", "start", "end", "nbase")] + \
+               [("beta", C.POINTER(C.c_double)), ("fnv", C.POINTER(C.c_uint64)), ("cells", C.POINTER(C.c_int32))]
+
+
 def build(force=False):
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC, "-j8", "libepihip.so"]
@@ -85,6 +91,9 @@ _SIGS = {
     "epi_batch_threshold_reads_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _VP]),
     "epi_batch_get_xm_beta_dev": (C.c_int, [_VP, _CS, _CS, _VP, _VP]),
     "epi_batch_match_target_dev": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "epi_batch_extract_patterns": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _CS, _F64, _I32, _I32, _VP, _I32, _VP,
+                                           C.POINTER(PatternTable)]),
+    "epi_pattern_table_free": (None, [C.POINTER(PatternTable)]),
     "epi_batch_cx_report_dev": (C.c_int, [_VP, _VP, _CS, _VP, C.POINTER(_I64)]),
     "epi_batch_cx_fetch_dev": (C.c_int, [_VP, C.POINTER(_VP), _VP]),
     "epi_batch_cx_fetch_host": (C.c_int, [_VP, C.POINTER(_VP), _VP]),

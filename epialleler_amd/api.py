@@ -276,6 +276,45 @@ def rcpp_mhl_report(df, ctx, hmax, hmin, max_ooctx_meth_frac, as_device=False):
     return Report(dict(zip(names, cols)), bam.levels)
 
 
+PATTERN_LEVELS = ("NA1", "H", "A", "C", "NA5", "X", "Z", "NA8", "NA9", "h", "G", "T", "N", "x", "z", "NA16")   # :192-195
+NA_INTEGER = -2 ** 31
+
+
+def rcpp_extract_patterns(df, target_rname, target_start, target_end, min_overlap, ctx, min_ctx_freq, clip,
+                          reverse_offset, hlght=()):
+    """src/rcpp_extract_patterns.cpp:26-211 -> Report with seqnames, strand, start, end, nbase, beta, pattern (16 hex
+    digits) and one int32 column per position (context / base factor codes, levels PATTERN_LEVELS, NA = -2^31), or an
+    empty Report when no pattern was found."""
+    lib = _lib.load()
+    bam = _as_bam(df)
+    b = bam.batch()
+    hl = np.ascontiguousarray(hlght, dtype=np.int32)
+    t = _lib.PatternTable()
+    _lib.check(lib.epi_batch_extract_patterns(b, int(target_rname), int(target_start), int(target_end), int(min_overlap),
+                                              _lib.enc(ctx), float(min_ctx_freq), int(bool(clip)), int(reverse_offset),
+                                              C.c_void_p(hl.ctypes.data) if hl.size else None, int(hl.size),
+                                              _stream(bam.device), C.byref(t)))
+    try:
+        k, m = int(t.npat), int(t.ncol)
+        if k == 0:
+            return Report({}, bam.levels)
+        take = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+        cols = {"seqnames": np.full(k, int(target_rname), np.int32)}
+        for nm in ("strand", "start", "end", "nbase"):
+            cols[nm] = take(getattr(t, nm), k, np.int32)
+        cols["beta"] = take(t.beta, k, np.float64)
+        cols["pattern"] = np.asarray(["%016X" % int(v) for v in take(t.fnv, k, np.uint64)], object)      # :174-176
+        pos = take(t.positions, m, np.int32)
+        cells = take(t.cells, m * k, np.int32).reshape(m, k)
+        for i in range(m):
+            cols[str(int(pos[i]))] = cells[i]
+    finally:
+        lib.epi_pattern_table_free(C.byref(t))
+    rep = Report(cols, bam.levels)
+    rep.pattern_levels = PATTERN_LEVELS
+    return rep
+
+
 # ---- exported R API ------------------------------------------------------------------------------
 
 def _match_arg(value, choices, name):

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 from .api import (CONTEXT_TO_BASES, Report, _CTX_CHOICES, _as_bam, _match_arg, _stream, preprocessBam,
-                  rcpp_get_xm_beta, rcpp_threshold_reads, writeReport)
+                  rcpp_extract_patterns, rcpp_get_xm_beta, rcpp_threshold_reads, writeReport)
 
 NA_INTEGER = -2 ** 31
 
@@ -168,3 +168,33 @@ def generateBedEcdf(bam, bed, bed_type=None, bed_rows=(1,), zero_based_bed=False
         sel = (match < 0) if r is None else (match == r)
         out[None if r is None else names[r - 1]] = {"context": Ecdf(ctx_beta[sel]), "out.of.context": Ecdf(oo_beta[sel])}
     return out
+
+
+def extractPatterns(bam, bed, bed_row=1, zero_based_bed=False, match_min_overlap=1, extract_context=None,
+                    min_context_freq=0.01, clip_patterns=False, strand_offset=None, highlight_positions=(), verbose=False,
+                    **preprocess_args):
+    """R/extractPatterns.R:107-143 + .getPatterns (R/internal.R:683-714).  bed: a path, a Bed, or a string
+    "chr:start-end"; bed_row is 1-based.  The result carries the BED row it belongs to in `.bed`."""
+    extract_context = _match_arg(extract_context, _CTX_CHOICES, "extract.context")
+    if strand_offset is None:
+        strand_offset = {"CG": 1, "CHG": 2, "CHH": 0, "CxG": 0, "CX": 0}[extract_context]
+    if isinstance(bed, str) and ":" in bed and "-" in bed.rsplit(":", 1)[1] and not __import__("os").path.exists(bed):
+        chrom, rng = bed.rsplit(":", 1)                                        # as("chr:start-end", "GRanges")
+        a, b_ = rng.split("-")
+        bed = Bed([chrom], [int(a)], [int(b_)])
+    elif not isinstance(bed, Bed):
+        bed = readBed(bed, zero_based_bed)
+    bam = _as_bam(preprocessBam(bam, **preprocess_args))
+    row = int(np.atleast_1d(bed_row)[0]) - 1
+    if row < 0 or row >= len(bed):
+        return Report({}, bam.levels)                                          # data.table()[bed.row] of a missing row: no target
+    levels = list(bam.levels) if bam.levels is not None else []
+    chrom = bed.chrom[row]
+    seq = levels.index(chrom) + 1 if chrom in levels else NA_INTEGER           # factor(seqnames, levels=levels(rname))
+    start, end = int(bed.start[row]), int(bed.end[row])
+    hl = sorted({int(p) for p in np.atleast_1d(np.asarray(highlight_positions, np.int64)) if start <= int(p) <= end})
+    c = CONTEXT_TO_BASES[extract_context]
+    rep = rcpp_extract_patterns(bam, seq, start, end, match_min_overlap, c["ctx_meth"] + c["ctx_unmeth"], min_context_freq,
+                                clip_patterns, int(strand_offset), hl)
+    rep.bed = bed.names()[row]
+    return rep

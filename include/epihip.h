@@ -186,6 +186,26 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin,
 int epi_batch_mhl_fetch_dev(epi_batch *b, int32_t *const d_icols[5], double *const d_dcols[2], void *stream);
 int epi_batch_mhl_fetch_host(epi_batch *b, int32_t *const h_icols[5], double *const h_dcols[2], void *stream);
 
+/* rcpp_extract_patterns (src/rcpp_extract_patterns.cpp:26-211; caller .getPatterns, R/internal.R:683-714):
+ * methylation patterns of the reads overlapping one target.  Library-owned host table: per pattern strand, start,
+ * end, nbase, beta, the FNV-1a hash the R side prints as 16 hex digits ("pattern"), the ordered column positions
+ * and cells[col * npat + p] = context index / base factor code (levels as :192-195) or INT32_MIN (NA).
+ * npat = 0 is the reference's empty data frame.  Synchronises `stream`. */
+typedef struct {
+  int64_t npat;
+  int32_t ncol;
+  int32_t *positions;                       /* [ncol] */
+  int32_t *strand, *start, *end, *nbase;    /* [npat] */
+  double *beta;                             /* [npat] */
+  uint64_t *fnv;                            /* [npat] */
+  int32_t *cells;                           /* [ncol][npat] */
+} epi_pattern_table;
+int epi_batch_extract_patterns(epi_batch *b, int32_t target_rname, int32_t target_start, int32_t target_end,
+                               int32_t min_overlap, const char *ctx, double min_ctx_freq, int32_t clip,
+                               int32_t reverse_offset, const int32_t *hlght /* sorted, unique, inside the target */,
+                               int32_t nhlght, void *stream, epi_pattern_table *out);
+void epi_pattern_table_free(epi_pattern_table *t);
+
 /* ---- multi-GPU (row-range shards; see DESIGN.md "Multi-GPU") -------------
  * Tiles are cut on an absolute position grid (epi_tile_positions() wide), so
  * ranks agree on tile boundaries.  A rank (a) reports the range of tile keys

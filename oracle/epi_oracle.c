@@ -360,3 +360,141 @@ int orc_mhl_report(const uint8_t *xm, const int64_t *off, const int32_t *templid
   dcols_out[0] = res_hlen.p;  dcols_out[1] = res_mhl.p;
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* rcpp_extract_patterns.cpp:26-211.                       */
+/* The reference keeps positions in ordered maps; here the same order comes  */
+/* from sorting.  Quirks kept as they are: with clip=TRUE the byte loop runs */
+/* to `overlap`, not to begin+overlap (:86,:132); position bytes enter the   */
+/* FNV-1a hash through a (signed) char pointer (:148,:163; epialleleR.h:8-13)*/
+/* Outputs (malloc'ed, release with orc_free): per pattern strand, start,    */
+/* end, nbase, beta, hash; the sorted column positions; cells[col*npat + p]  */
+/* = context / base factor code or INT32_MIN (NA).                           */
+static int cmp_i32(const void *a, const void *b) {
+  const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+  return x < y ? -1 : x > y;
+}
+
+static void fnv_add_char(uint64_t *h, const void *p, unsigned size) {       /* pointer of type (signed) char */
+  const signed char *c = (const signed char *)p;
+  for (unsigned i = 0; i < size; i++) { *h ^= (uint64_t)(int64_t)c[i]; *h *= 1099511628211ull; }
+}
+
+int orc_extract_patterns(const uint8_t *xm, const int64_t *off, const int32_t *templid,
+                         const int32_t *rname, const int32_t *strand, const int32_t *start, int64_t n,
+                         unsigned int target_rname, unsigned int target_start, unsigned int target_end,
+                         int min_overlap, const char *ctx, double min_ctx_freq, int clip,
+                         unsigned int reverse_offset, const int32_t *hlght, int32_t nhlght,
+                         int64_t *npat_out, int32_t *ncol_out, int32_t **o_strand, int32_t **o_start, int32_t **o_end,
+                         int32_t **o_nbase, double **o_beta, uint64_t **o_fnv, int32_t **o_pos, int32_t **o_cells)
+{
+  static const unsigned int factor_map[16] = { 13, 3, 4, 13, 11, 13, 13, 13, 12, 13, 13, 13, 13, 13, 13, 13 };   /* :47 */
+  unsigned int ctx_map[16] = {0};                                           /* :61-64 */
+  for (const char *c = ctx; *c; c++) ctx_map[CTX_TO_IDX(*c)] = 1;
+  /* first pass (:74-100): how often is every in-context position seen; npat = reads that overlap the target */
+  ivec allpos; memset(&allpos, 0, sizeof(allpos));
+  unsigned int npat = 0;
+  for (int64_t x = 0; x < n; x++) {
+    if (rname[x] != (int)target_rname) continue;
+    const int64_t t = templid ? templid[x] : x;
+    const unsigned int size_x = (unsigned int)(off[t + 1] - off[t]);
+    const unsigned int start_x = (unsigned int)start[x];
+    const unsigned int end_x = start_x + size_x - 1;
+    const unsigned int over_start_x = start_x > target_start ? start_x : target_start;
+    const unsigned int over_end_x = end_x < target_end ? end_x : target_end;
+    const int overlap = (int)(over_end_x - over_start_x + 1);
+    if (overlap >= min_overlap) {
+      const uint8_t *s = xm + off[t];
+      const unsigned int offset_x = strand[x] == 2 ? reverse_offset : 0;
+      const unsigned int begin_i = clip ? (over_start_x - start_x) : 0;
+      const unsigned int end_i = clip ? (unsigned int)overlap : size_x;
+      for (unsigned int i = begin_i; i < end_i; i++)
+        if (ctx_map[UNPACK_CTX_IDX(s[i])]) ivec_push(&allpos, (int32_t)(start_x + i - offset_x));
+      npat++;
+    }
+  }
+  qsort(allpos.p, allpos.n, sizeof(int32_t), cmp_i32);
+  /* valid positions (:103-108), highlight positions (:110-112), merged and ordered (:185) */
+  ivec cols; memset(&cols, 0, sizeof(cols));
+  for (size_t i = 0; i < allpos.n;) {
+    size_t j = i;
+    while (j < allpos.n && allpos.p[j] == allpos.p[i]) j++;
+    int is_h = 0;
+    for (int32_t k = 0; k < nhlght; k++) if (hlght[k] == allpos.p[i]) is_h = 1;
+    if ((double)(j - i) / npat >= min_ctx_freq && !is_h) ivec_push(&cols, allpos.p[i]);
+    i = j;
+  }
+  const size_t npatcols = cols.n;
+  for (int32_t k = 0; k < nhlght; k++) ivec_push(&cols, hlght[k]);
+  /* column kind before sorting: remember which positions are pattern columns */
+  int32_t *patcols = (int32_t *)malloc((npatcols + 1) * sizeof(int32_t));
+  memcpy(patcols, cols.p, npatcols * sizeof(int32_t));
+  qsort(cols.p, cols.n, sizeof(int32_t), cmp_i32);
+  const size_t ncol = cols.n;
+  const size_t cap = npat ? npat : 1;
+  int32_t *cells = (int32_t *)malloc((ncol * cap + 1) * sizeof(int32_t));
+  for (size_t i = 0; i < ncol * cap; i++) cells[i] = INT32_MIN;
+  ivec st, sa, en, nb; dvec be;
+  memset(&st, 0, sizeof(st)); memset(&sa, 0, sizeof(sa)); memset(&en, 0, sizeof(en)); memset(&nb, 0, sizeof(nb)); memset(&be, 0, sizeof(be));
+  uint64_t *fnvs = (uint64_t *)malloc((cap + 1) * sizeof(uint64_t));
+  unsigned int np2 = 0;
+  for (int64_t x = 0; x < n; x++) {                                         /* second pass (:115-181) */
+    if (rname[x] != (int)target_rname) continue;
+    const int64_t t = templid ? templid[x] : x;
+    const unsigned int size_x = (unsigned int)(off[t + 1] - off[t]);
+    const unsigned int start_x = (unsigned int)start[x];
+    const unsigned int end_x = start_x + size_x - 1;
+    const unsigned int over_start_x = start_x > target_start ? start_x : target_start;
+    const unsigned int over_end_x = end_x < target_end ? end_x : target_end;
+    const int overlap = (int)(over_end_x - over_start_x + 1);
+    if (overlap < min_overlap) continue;
+    const uint8_t *s = xm + off[t];
+    const unsigned int offset_x = strand[x] == 2 ? reverse_offset : 0;
+    const unsigned int begin_i = clip ? (over_start_x - start_x) : 0;
+    const unsigned int end_i = clip ? (unsigned int)overlap : size_x;
+    unsigned int meth = 0, total = 0;
+    uint64_t fnv = 14695981039346656037ull;
+    for (unsigned int i = begin_i; i < end_i; i++) {
+      const unsigned int base = UNPACK_CTX_IDX(s[i]);
+      if (!ctx_map[base]) continue;
+      const unsigned int pos = start_x + i - offset_x;
+      const int32_t key = (int32_t)pos;
+      const int32_t *hit = (const int32_t *)bsearch(&key, patcols, npatcols, sizeof(int32_t), cmp_i32);
+      if (!hit) continue;                                                   /* :141 */
+      const int32_t *col = (const int32_t *)bsearch(&key, cols.p, ncol, sizeof(int32_t), cmp_i32);
+      cells[(size_t)(col - cols.p) * cap + np2] = (int32_t)base;            /* :143 */
+      meth += !(base & 8);
+      total++;
+      fnv_add_char(&fnv, &pos, sizeof(pos));                                /* :147 */
+      fnv ^= (uint64_t)base; fnv *= 1099511628211ull;                       /* :148: *(const unsigned int*)&base, one step */
+    }
+    if (fnv == 14695981039346656037ull) continue;                           /* :152 */
+    for (int32_t k = 0; k < nhlght; k++) {                                  /* :154-164 */
+      const unsigned int hp = (unsigned int)hlght[k] - start_x;
+      if (hp >= begin_i && hp < end_i) {
+        const unsigned int base = factor_map[(s[hp] >> 4) & 15u];
+        const int32_t key = hlght[k];
+        const int32_t *col = (const int32_t *)bsearch(&key, cols.p, ncol, sizeof(int32_t), cmp_i32);
+        cells[(size_t)(col - cols.p) * cap + np2] = (int32_t)base;
+        fnv_add_char(&fnv, &hlght[k], sizeof(int32_t));
+        fnv ^= (uint64_t)base; fnv *= 1099511628211ull;
+      }
+    }
+    ivec_push(&st, strand[x]);
+    ivec_push(&sa, (int32_t)(start_x + begin_i));
+    ivec_push(&en, (int32_t)(start_x + end_i - 1));
+    ivec_push(&nb, (int32_t)total);
+    dvec_push(&be, (double)meth / total);
+    fnvs[np2] = fnv;
+    np2++;
+  }
+  /* compact the cell matrix to np2 patterns per column (:187-189) */
+  int32_t *out = (int32_t *)malloc((ncol * (size_t)(np2 ? np2 : 1) + 1) * sizeof(int32_t));
+  for (size_t c = 0; c < ncol; c++)
+    for (unsigned int p = 0; p < np2; p++) out[c * np2 + p] = cells[c * cap + p];
+  free(cells); free(patcols); free(allpos.p);
+  *npat_out = np2;
+  *ncol_out = np2 ? (int32_t)ncol : 0;
+  *o_strand = st.p; *o_start = sa.p; *o_end = en.p; *o_nbase = nb.p; *o_beta = be.p; *o_fnv = fnvs; *o_pos = cols.p; *o_cells = out;
+  return 0;
+}

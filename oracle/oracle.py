@@ -70,7 +70,7 @@ def _take(ptr, n, dtype):
     if n == 0 or not ptr:
         out = np.zeros(0, dtype)
     else:
-        ct = C.c_int32 if dtype == np.int32 else C.c_double
+        ct = {np.int32: C.c_int32, np.uint64: C.c_uint64}.get(dtype, C.c_double)
         out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).astype(dtype, copy=True)
     if ptr:
         lib().orc_free(ptr)
@@ -106,4 +106,27 @@ def mhl_report(xm, off, rname, strand, start, ctx, hmax=0, hmin=0, max_ooctx_met
            for i, k in enumerate(["rname", "strand", "pos", "context", "coverage"])}
     out["length"] = _take(dcols[0], nrow.value, np.float64)
     out["lmhl"] = _take(dcols[1], nrow.value, np.float64)
+    return out
+
+
+def extract_patterns(xm, off, rname, strand, start, target_rname, target_start, target_end, min_overlap, ctx,
+                     min_ctx_freq, clip, reverse_offset, hlght=()):
+    """rcpp_extract_patterns: dict with per-pattern strand/start/end/nbase (int32), beta (float64), fnv (uint64),
+    the sorted column positions and cells[ncol, npat] (context / base factor codes, INT32_MIN = NA)."""
+    xm, off, rname, strand, start, _ = _prep(xm, off, rname, strand, start)
+    n = off.size - 1
+    hl = np.ascontiguousarray(hlght, dtype=np.int32)
+    npat, ncol = C.c_int64(0), C.c_int32(0)
+    ptrs = [C.c_void_p() for _ in range(8)]
+    lib().orc_extract_patterns(_p(xm, C.c_uint8), _p(off, C.c_int64), None, _p(rname, C.c_int32), _p(strand, C.c_int32),
+                               _p(start, C.c_int32), C.c_int64(n), C.c_uint(target_rname), C.c_uint(target_start),
+                               C.c_uint(target_end), C.c_int(min_overlap), ctx.encode("latin1"), C.c_double(min_ctx_freq),
+                               C.c_int(int(bool(clip))), C.c_uint(reverse_offset), _p(hl, C.c_int32) if hl.size else None,
+                               C.c_int32(hl.size), C.byref(npat), C.byref(ncol), *[C.byref(p) for p in ptrs])
+    k, m = npat.value, ncol.value
+    out = {nm: _take(ptrs[i], k, np.int32) for i, nm in enumerate(["strand", "start", "end", "nbase"])}
+    out["beta"] = _take(ptrs[4], k, np.float64)
+    out["fnv"] = _take(ptrs[5], k, np.uint64)
+    out["positions"] = _take(ptrs[6], m, np.int32)
+    out["cells"] = _take(ptrs[7], m * k, np.int32).reshape(m, k)
     return out

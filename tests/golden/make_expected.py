@@ -7,6 +7,7 @@ Run in the build container (needs /root/reference):
 Sources (reference inst/unitTests/):
     test_generateCytosineReport.R:1-260, test_generateMhlReport.R:1-123,
     test_generateCytosineReport.R:262-433 (long-read MM/ML cases: inputs and expected tables),
+    test_extractPatterns.R:1-270 (every numeric expectation, in file order),
     test_simulateBam.R:53-87, test_generateBedReport.R:12-83,
     test_preprocessBam.R:11-15
 plus the survey-time probe outputs recorded in SURVEY.md section 8c.
@@ -55,6 +56,25 @@ def collect(fn):
     for a in blocks(fn):
         if len(a) >= 2 and re.match(r"^(c\()?[-\d\s.,eE]+\)?$", a[1]):
             out.append({"expr": a[0], "value": nums(a[1])})
+    return out
+
+
+def collect_na(fn):
+    """As collect(), but integer vectors may hold NA (-> null) and a:b ranges (test_extractPatterns.R)."""
+    out = []
+    for a in blocks(fn):
+        if len(a) < 2 or not re.match(r"^(c\()?[-\d\s.,:NA]+\)*$", a[1]):
+            continue
+        vals = []
+        for tok in re.findall(r"NA|-?\d+:-?\d+|-?\d+", a[1]):
+            if tok == "NA":
+                vals.append(None)
+            elif ":" in tok:
+                lo, hi = tok.split(":")
+                vals += list(range(int(lo), int(hi) + 1))
+            else:
+                vals.append(int(tok))
+        out.append({"expr": a[0], "value": vals})
     return out
 
 
@@ -143,6 +163,7 @@ exp = {
     "simulateBam": collect("test_simulateBam.R"),
     "generateBedReport": collect("test_generateBedReport.R"),
     "longRead": long_read_cases(),
+    "extractPatterns": collect_na("test_extractPatterns.R"),
     # Recorded at survey time from the unmodified reference objects;
     # not reproducible in this image (reference unbuildable), kept as extra pins.
     "survey_probe": {
