@@ -8,7 +8,7 @@
 //   k_pat_extract  one thread per overlapping read: its cell per valid position, methylated / total counts and the
 //                  FNV-1a hash of (position, base) pairs, highlighted bases appended (:133-166)
 //   host           drops empty patterns (:152) and returns the table.
-// Quirks of the reference kept as they are (the oracle does the same): with clip=TRUE the byte loop ends at `overlap`,
+// Quirks of the reference kept as they are: with clip=TRUE the byte loop ends at `overlap`,
 // not at begin+overlap (:86,:132), and position bytes enter the hash sign-extended (char pointer, epialleleR.h:8-13).
 #include "common.hpp"
 #include <stdlib.h>
