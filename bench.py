@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--read-len", type=int, default=0, help="override the template length of the workload (experiments)")
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="rows timed on the CPU oracle (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
@@ -81,7 +82,7 @@ def main():
     rows = args.rows or wl["rows"]
     if wl.get("strong"):
         rows = (rows + world - 1) // world                      # fixed total: BASELINE config 3 is a strong-scaling case
-    L = wl["read_len"]
+    L = args.read_len or wl["read_len"]
     n_total = rows * world
     bam = synth.generate_device(n_total=n_total, read_len=L, row_first=rank * rows, n=rows, device=local)
     torch.cuda.synchronize()

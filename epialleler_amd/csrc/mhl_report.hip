@@ -114,38 +114,53 @@ __device__ __forceinline__ uint32_t plane_nibble(uint32_t f, int bit) {
   return t & 0xFu;
 }
 
-// The 16*C bytes at g0 (16-byte aligned) of the row [rs,re): per-byte bit masks.
+// The 16*C bytes at g0 (16-byte aligned) of the row [rs,re), loaded (so that a caller can have the next chunk's loads
+// in flight while it works on this one) ...
+template <int C> struct ChunkRaw { uint32_t ww[4 * C]; int lo, hi; };       // hi <= lo: nothing of the row in this chunk
+
 template <int C>
-__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk(const uint8_t *__restrict__ xm, int64_t g0, bool live,
-                                                                   int64_t rs, int64_t re, const MhlLut &lut) {
-  using M = typename MaskOf<C>::T;
+__device__ __forceinline__ ChunkRaw<C> mhl_chunk_load(const uint8_t *__restrict__ xm, int64_t g0, bool live, int64_t rs, int64_t re) {
   constexpr int W = 16 * C;
-  Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
-  if (!live) return c;
+  ChunkRaw<C> r;
+  r.lo = 0; r.hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4 * C; j++) r.ww[j] = 0u;
+  if (!live) return r;
   int64_t lo = rs - g0, hi = re - g0;
   if (lo < 0) lo = 0;
   if (hi > W) hi = W;
-  if (hi <= lo) return c;
-  uint32_t ww[4 * C];
+  if (hi <= lo) return r;
+  r.lo = (int)lo; r.hi = (int)hi;
 #pragma unroll
   for (int j = 0; j < C; j++) {
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (j == 0 || g0 + 16 * j < re) w = *reinterpret_cast<const uint4 *>(xm + g0 + 16 * j);
-    ww[4 * j] = w.x; ww[4 * j + 1] = w.y; ww[4 * j + 2] = w.z; ww[4 * j + 3] = w.w;
+    r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
   }
-  c.V = bm_below<M>((int)hi) & ~bm_below<M>((int)lo);
+  return r;
+}
+
+// ... and turned into per-byte bit masks.
+template <int C>
+__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk_masks(const ChunkRaw<C> &r, const MhlLut &lut) {
+  using M = typename MaskOf<C>::T;
+  constexpr int W = 16 * C;
+  Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
+  if (r.hi <= r.lo) return c;
+  const int lo = r.lo, hi = r.hi;
+  c.V = bm_below<M>(hi) & ~bm_below<M>(lo);
   // bytes outside the row get flag 0: byte masks of the row within each dword (only edge chunks need them)
   const bool edge = lo > 0 || hi < W;
   uint32_t f8[4 * C], kacc = 0;
 #pragma unroll
   for (int d = 0; d < 4 * C; d++) {
-    const uint32_t c4 = ww[d] & 0x0F0F0F0Fu;
+    const uint32_t c4 = r.ww[d] & 0x0F0F0F0Fu;
     const uint32_t lo3 = c4 & 0x07070707u;
     const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
     uint32_t f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
                                        __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
     if (edge) {
-      int a = (int)lo - 4 * d, b = (int)hi - 4 * d;           // valid bytes [a, b) of this dword
+      int a = lo - 4 * d, b = hi - 4 * d;                     // valid bytes [a, b) of this dword
       a = a < 0 ? 0 : (a > 4 ? 4 : a);
       b = b < 0 ? 0 : (b > 4 ? 4 : b);
       const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
@@ -163,6 +178,12 @@ __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk(const uint8_t 
     for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
   }
   return c;
+}
+
+template <int C>
+__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk(const uint8_t *__restrict__ xm, int64_t g0, bool live,
+                                                                   int64_t rs, int64_t re, const MhlLut &lut) {
+  return mhl_chunk_masks<C>(mhl_chunk_load<C>(xm, g0, live, rs, re), lut);
 }
 
 template <class M> __device__ __forceinline__ uint32_t lead_members(const Chunk<M> &c) {    // members before the first cut (all if none)
@@ -260,7 +281,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     anyk |= __shfl_xor(anyk, d, 64);
   }
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
-  if (keep && sub == 0 && h > __atomic_load_n(a.max_h, __ATOMIC_RELAXED)) atomicMax(a.max_h, h);   // rarely taken after the first waves
+  // the current maximum is read from L2 (an L1 copy would stay 0 and every read would issue the atomic: 67 ms)
+  if (keep && sub == 0 && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
   const M P = (keep && !(a.ablate & 4)) ? span_bits<W>(c, enter, cont) : (M)0;
   const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);
@@ -312,9 +334,15 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   const int64_t bi = (rs >> MHL_BLK_SHIFT) + 2 * row;        // this read's slots in blkrec / cont (>= nblk of them)
   uint32_t h = 0, oo_m = 0, oo_u = 0, anyk = 0;
   uint32_t from_right = 0;
+  auto load_blk = [&](int64_t b) {                           // this lane's 32 bytes of block b (none outside [0, nblk))
+    const int64_t ci = c0 + b * 64 + lane;
+    return mhl_chunk_load<2>(a.xm, ci << 5, b >= 0 && b < nblk && ci < c1, rs, re);
+  };
+  ChunkRaw<2> raw = load_blk(nblk - 1);
   for (int64_t b = nblk - 1; b >= 0; b--) {
-    const int64_t cidx = c0 + b * 64 + lane;
-    const Chunk<uint32_t> c = mhl_chunk<2>(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    const ChunkRaw<2> nxt = load_blk(b - 1);                 // in flight during this block's scans
+    const Chunk<uint32_t> c = mhl_chunk_masks<2>(raw, a.lut);
+    raw = nxt;
     h += __popc(c.U | c.L); oo_m += c.oom; oo_u += c.oou; anyk |= c.K ? 1u : 0u;
     Seg sf = {c.L ? 1u : 0u, lead_members(c)};
 #pragma unroll
@@ -323,7 +351,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
       r.has = __shfl_down(sf.has, d, 64); r.cnt = __shfl_down(sf.cnt, d, 64);
       if (lane + d < 64) sf = seg_combine(r, sf);
     }
-    if (lane == 0) __atomic_store_n(a.cont + bi + b, from_right, __ATOMIC_RELAXED);
+    if (lane == 0) __hip_atomic_store(a.cont + bi + b, from_right, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // to L2, read back below
     const uint32_t bh = __shfl(sf.has, 0, 64), bc = __shfl(sf.cnt, 0, 64);
     from_right = bh ? bc : bc + from_right;
   }
@@ -336,13 +364,17 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   }
   const bool keep = mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   if (lane == 0) a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, 0, 0);
-  if (keep && lane == 0 && h > __atomic_load_n(a.max_h, __ATOMIC_RELAXED)) atomicMax(a.max_h, h);
+  if (keep && lane == 0 && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
   if (!keep) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // the stores above have left the wave (no cache maintenance needed:
+                                                             // the loads below are agent-scope, i.e. served by L2)
   Seg carry = {0u, 0u};
+  raw = load_blk(0);
   for (int64_t b = 0; b < nblk; b++) {
     const int64_t cidx = c0 + b * 64 + lane;
-    const Chunk<uint32_t> c = mhl_chunk<2>(a.xm, cidx << 5, cidx < c1, rs, re, a.lut);
+    const ChunkRaw<2> nxt = load_blk(b + 1);
+    const Chunk<uint32_t> c = mhl_chunk_masks<2>(raw, a.lut);
+    raw = nxt;
     Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
     Seg last;
     last.has = __shfl(pf.has, 63, 64); last.cnt = __shfl(pf.cnt, 63, 64);
     carry = seg_combine(carry, last);
-    const uint32_t right = __atomic_load_n(a.cont + bi + b, __ATOMIC_RELAXED);
+    const uint32_t right = __hip_atomic_load(a.cont + bi + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t cont = exr.has ? exr.cnt : exr.cnt + right;
     const uint32_t P = span_bits<32>(c, enter, cont);
     const uint32_t Q = anyk ? (c.V & ~c.K) : 0u;

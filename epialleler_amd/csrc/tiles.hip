@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
   }
   if ((threadIdx.x & 63) == 0) {
     // uniform-length input: after the first few waves the cached maximum already covers `len`
-    if (len > __atomic_load_n(&st->max_len, __ATOMIC_RELAXED)) atomicMax(&st->max_len, len);
+    if (len > __hip_atomic_load(&st->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_len, len);   // read from L2
     if (unsorted) atomicOr(&st->unsorted, 1);
     if (bad_strand) atomicOr(&st->bad_strand, 1);
     if (bad_len) atomicOr(&st->bad_len, 1);
