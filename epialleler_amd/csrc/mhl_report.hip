@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   }
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   // the current maximum is read from L2 (an L1 copy would stay 0 and every read would issue the atomic: 67 ms)
-  if (keep && sub == 0 && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
+  if (keep && sub == 0 && !(a.ablate & 8) && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
   const M P = (keep && !(a.ablate & 4)) ? span_bits<W>(c, enter, cont) : (M)0;
   const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);

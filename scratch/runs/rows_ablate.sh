@@ -4,6 +4,4 @@ run() { timeout -k 10 280 python bench.py --workload cfg4 --steps 3 --warmup 1 -
 import json,sys
 d=json.loads(sys.stdin.read()); print('$1', d['roofline']['kernel_ms_all'])"; }
 run base
-EPIHIP_MHL_ABLATE=256 run noatomic
-EPIHIP_MHL_ABLATE=768 run noatomic_nowrite
-EPIHIP_MHL_ABLATE=1792 run noatomic_nowrite_nospan
+EPIHIP_MHL_ABLATE=2048 EPIHIP_MHL_SUMS=64 run nomaxh
