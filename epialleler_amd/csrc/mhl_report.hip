@@ -151,28 +151,47 @@ __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk_masks(const Ch
   c.V = bm_below<M>(hi) & ~bm_below<M>(lo);
   // bytes outside the row get flag 0: byte masks of the row within each dword (only edge chunks need them)
   const bool edge = lo > 0 || hi < W;
-  uint32_t f8[4 * C], kacc = 0;
+  uint32_t f8[4 * C], kacc = 0, cm = 0, cn = 0;
+  // Bit planes by v_dot4_u32_u8: the flag bit of four bytes times the weights (1,2,4,8) is their nibble; a second
+  // dword with weights (16,32,64,128) completes a mask byte, which is shifted into place (the cut flag is bit 1, so
+  // its sums come out doubled: one bit further down).  Counts of the out-of-context flags the same way with weights 1.
+  uint32_t ulo = 0, uhi = 0, llo = 0, lhi = 0;           // mask bits 0-31 / 32-63
 #pragma unroll
-  for (int d = 0; d < 4 * C; d++) {
-    const uint32_t c4 = r.ww[d] & 0x0F0F0F0Fu;
-    const uint32_t lo3 = c4 & 0x07070707u;
-    const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
-    uint32_t f = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
-                                       __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
-    if (edge) {
-      int a = lo - 4 * d, b = hi - 4 * d;                     // valid bytes [a, b) of this dword
-      a = a < 0 ? 0 : (a > 4 ? 4 : a);
-      b = b < 0 ? 0 : (b > 4 ? 4 : b);
-      const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
-      f &= bm;
+  for (int e = 0; e < 2 * C; e++) {
+    uint32_t f[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int d = 2 * e + h;
+      const uint32_t c4 = r.ww[d] & 0x0F0F0F0Fu;
+      const uint32_t lo3 = c4 & 0x07070707u;
+      const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
+      uint32_t v = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
+                                         __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+      if (edge) {
+        int a = lo - 4 * d, b = hi - 4 * d;                   // valid bytes [a, b) of this dword
+        a = a < 0 ? 0 : (a > 4 ? 4 : a);
+        b = b < 0 ? 0 : (b > 4 ? 4 : b);
+        const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
+        v &= bm;
+      }
+      f[h] = v;
+      f8[d] = v;
+      kacc |= v;
+      cm = __builtin_amdgcn_udot4(v & 0x08080808u, 0x01010101u, cm, false);     // 8 x count
+      cn = __builtin_amdgcn_udot4(v & 0x10101010u, 0x01010101u, cn, false);     // 16 x count
     }
-    f8[d] = f;
-    kacc |= f;
-    c.U |= (M)plane_nibble(f, 0) << (4 * d);
-    c.L |= (M)plane_nibble(f, 1) << (4 * d);
-    c.oom = __builtin_amdgcn_sad_u8((f >> 3) & 0x01010101u, 0u, c.oom);
-    c.oou = __builtin_amdgcn_sad_u8((f >> 4) & 0x01010101u, 0u, c.oou);
+    const uint32_t ub = __builtin_amdgcn_udot4(f[1] & 0x01010101u, 0x80402010u,
+                                               __builtin_amdgcn_udot4(f[0] & 0x01010101u, 0x08040201u, 0u, false), false);
+    const uint32_t lb2 = __builtin_amdgcn_udot4(f[1] & 0x02020202u, 0x80402010u,
+                                                __builtin_amdgcn_udot4(f[0] & 0x02020202u, 0x08040201u, 0u, false), false);
+    const int sh = 8 * (e & 3);
+    if (e < 4) { ulo |= ub << sh; llo |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
+    else { uhi |= ub << sh; lhi |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
   }
+  c.U = (M)ulo; c.L = (M)llo;
+  if constexpr (sizeof(M) == 8) { c.U |= (M)uhi << 32; c.L |= (M)lhi << 32; }
+  c.oom = cm >> 3;
+  c.oou = cn >> 4;
   if (kacc & 0x04040404u) {                                   // skipped bytes are rare ('+'/'-', filler between mates)
 #pragma unroll
     for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
