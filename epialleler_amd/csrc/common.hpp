@@ -83,6 +83,7 @@ struct epi_batch {
   // reusable workspace
   epi::DevBuf stats;        // RowStats of the batch (k_row_stats, queued once at creation)
   bool stats_queued = false, stats_host = false;
+  hipEvent_t stats_done = nullptr;          // recorded behind k_row_stats on the stream it was queued on
   epi::RowStats h_stats = {0, 0, 0, 0};   // host copy, fetched by the first report call (which raises the errors)
   epi::DevBuf scan_tmp;
   epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
@@ -125,6 +126,8 @@ int scan_block_sums_inplace(uint32_t *d_bsum, int64_t nb, uint32_t *d_total, hip
 // tile index (tiles.hip)
 // queue k_row_stats for a new batch (no sync, no error: per-read functions accept unsorted rows)
 int launch_row_stats(epi_batch *b, hipStream_t s);
+// host copy of the statistics (waits for the kernel whatever stream it was queued on); no validation
+int fetch_row_stats(epi_batch *b, hipStream_t s);
 // row statistics (validated: errors for bad offsets/strands/unsorted rows) + tile table; one host sync
 int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out);
 

@@ -491,8 +491,10 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     a.pool_meth = b->pool_a.as<uint32_t>();
     a.pool_unmeth = b->pool_b.as<uint32_t>();
     a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
-    EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
-    EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
+    if (attempt > 0) {                                   // (the tile-index pass zeroed them for the first attempt)
+      EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));         // cursor, total, heavy count
+      EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
+    }
     prof_begin("cx_tiles", s);
     launch_cx(false, T, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);

@@ -289,6 +289,7 @@ void epi_batch_free(epi_batch *b) {
                     &b->tile_out, &b->pool_key, &b->pool_a, &b->pool_b, &b->pool_c, &b->pool_d, &b->pool_e, &b->pool_f,
                     &b->misc, &b->mhl_m, &b->mhl_h, &b->mhl_blk, &b->mhl_cont, &b->mhl_cur, &b->d_shared_keys, &b->d_shared_owned, &b->heavy_list, &b->heavy_slab, &b->heavy_sums, &b->diag, &b->d_slot_tile};
   for (DevBuf *d : bufs) d->release();
+  if (b->stats_done) (void)hipEventDestroy(b->stats_done);
   delete b;
 }
 

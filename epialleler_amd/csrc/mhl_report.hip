@@ -1171,8 +1171,10 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     a.pool_nu = b->pool_e.as<unsigned long long>();
     a.pool_de = b->pool_f.as<unsigned long long>();
     a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
-    EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));           // cursor, total, heavy count
-    EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
+    if (attempt > 0) {                                   // (the tile-index pass zeroed them for the first attempt)
+      EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));         // cursor, total, heavy count
+      EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
+    }
     prof_begin("mhl_tiles", s);
     if (narrow) launch_mhl_tiles<uint32_t>(tg, nt, s, a); else launch_mhl_tiles<unsigned long long>(tg, nt, s, a);
     prof_end("mhl_tiles", s);

@@ -150,11 +150,7 @@ int epi_batch_extract_patterns(epi_batch *b, int32_t target_rname, int32_t targe
   if (b->n == 0) return EPI_OK;
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
-  if (!b->stats_host) {                                     // the longest read bounds the window of positions
-    if (!b->stats_queued) EPI_TRY(launch_row_stats(b, s));
-    EPI_TRY(read_scalars(b, s, b->stats.p, sizeof(RowStats), &b->h_stats));
-    b->stats_host = true;
-  }
+  EPI_TRY(fetch_row_stats(b, s));                           // the longest read bounds the window of positions
   if (b->h_stats.bad_len) return fail(EPI_ERR_ARG, "offsets are not non-decreasing, or start+length exceeds int32");
   const int64_t lmax = b->h_stats.max_len;
 

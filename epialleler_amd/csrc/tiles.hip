@@ -92,8 +92,12 @@ template <bool FILL>
 __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                            int64_t n, int32_t lmax, int32_t sh, uint32_t *__restrict__ bsum,
                                                            Tile *__restrict__ tiles, const int64_t *__restrict__ shared_keys,
-                                                           int32_t nshared, int32_t *__restrict__ slot_tile) {
+                                                           int32_t nshared, int32_t *__restrict__ slot_tile,
+                                                           uint32_t *__restrict__ misc) {
   __shared__ uint32_t s_tot[TB_ITEMS][TB_THREADS / 64];
+  if (FILL && blockIdx.x == 0 && threadIdx.x == 0) {       // the report kernels' counters start at zero (saves three memsets)
+    misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0;    // pool cursor, output rows, heavy tiles, largest heavy tile
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * TB_ROWS + threadIdx.x;     // item i is row base + i*TB_THREADS: coalesced
   uint32_t c[TB_ITEMS];
@@ -191,7 +195,18 @@ int launch_row_stats(epi_batch *b, hipStream_t s) {
     hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, b->stats.as<RowStats>());
     EPI_HIP(hipGetLastError());
   }
+  if (!b->stats_done) EPI_HIP(hipEventCreateWithFlags(&b->stats_done, hipEventDisableTiming));
+  EPI_HIP(hipEventRecord(b->stats_done, s));
   b->stats_queued = true;
+  return EPI_OK;
+}
+
+int fetch_row_stats(epi_batch *b, hipStream_t s) {
+  if (b->stats_host) return EPI_OK;
+  if (!b->stats_queued) EPI_TRY(launch_row_stats(b, s));
+  EPI_HIP(hipEventSynchronize(b->stats_done));              // the kernel may sit on another stream than `s`
+  EPI_TRY(read_scalars(b, s, b->stats.p, sizeof(RowStats), &b->h_stats));
+  b->stats_host = true;
   return EPI_OK;
 }
 
@@ -205,13 +220,8 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   EPI_TRY(b->misc.ensure(256));
   // misc layout (u32): [0] tile count, [1] pool cursor, [2] output rows, [3] heavy tiles, [8] largest heavy tile
   uint32_t *d_misc = b->misc.as<uint32_t>();
-  EPI_HIP(hipMemsetAsync(d_misc, 0, 16, s));
-  if (b->n == 0) return EPI_OK;
-  if (!b->stats_host) {
-    if (!b->stats_queued) EPI_TRY(launch_row_stats(b, s));
-    EPI_TRY(read_scalars(b, s, b->stats.p, sizeof(RowStats), &b->h_stats));
-    b->stats_host = true;
-  }
+  if (b->n == 0) { EPI_HIP(hipMemsetAsync(d_misc, 0, 36, s)); return EPI_OK; }
+  EPI_TRY(fetch_row_stats(b, s));
   *h = b->h_stats;
   if (h->bad_len) return fail(EPI_ERR_ARG, "offsets are not non-decreasing, or start+length exceeds int32");
   if (h->bad_strand) return fail(EPI_ERR_ARG, "strand values must be 1 ('+') or 2 ('-')");
@@ -223,7 +233,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   EPI_TRY(b->scan_tmp.ensure((size_t)nb * 4));
   uint32_t *bsum = b->scan_tmp.as<uint32_t>();
   hipLaunchKernelGGL((k_tile_pass<false>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
-                     (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr);
+                     (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr, d_misc);
   EPI_HIP(hipGetLastError());
   EPI_TRY(scan_block_sums_inplace(bsum, nb, d_misc, s));
   uint32_t nt = 0;
@@ -236,7 +246,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
     EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
   }
   hipLaunchKernelGGL((k_tile_pass<true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
-                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>());
+                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>(), d_misc);
   EPI_HIP(hipGetLastError());
   *ntiles_out = (int32_t)nt;
   return EPI_OK;
