@@ -569,7 +569,7 @@ __device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow 
 // position (+1 there, -1 after it, in the difference arrays).
 template <int OFF, bool FIRST, class ST>
 __device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice &m, const MhlLds<ST> &L) {
-  cx_add_dword<MHL_T, OFF, FIRST, true>(w, k, m.rs);
+  cx_add_dword<MHL_T, OFF, FIRST, true>(w, k == m.rs.nd - 1, m.rs);
   const uint32_t c4 = w & 0x0F0F0F0Fu;
   const uint32_t lo3 = c4 & 0x07070707u;
   const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);

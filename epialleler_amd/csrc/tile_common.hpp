@@ -36,7 +36,9 @@ struct RowSlice {                         // the part of one row that falls insi
                                           // in the order the lane walks its four bytes (see rot8)
   int rot8;                               // 8 * byte rotation: sub-step j handles byte (j + rot) & 3
   int nd;                                 // dwords in the slice (0 = nothing to do)
+  int tl;                                 // nd - 1 - sub: the lane's dword u*G is in the slice iff u*G <= tl, the last one iff ==
   uint32_t lc4;                           // 0x08080808 when the read failed thresholding (lower-case, :118)
+  uint32_t pick0;                         // 0x03020100 | lc4 >> 1: the v_perm selector that merges the two LUT halves
   uint32_t mask_first, mask_last;         // valid bytes of the slice's first / last dword
 };
 
@@ -63,7 +65,7 @@ __device__ __forceinline__ RowVals cx_load_row(const RowCols &a, const Tile &td,
 template <int T, int G, bool PK = false>
 __device__ __forceinline__ RowSlice cx_slice_of(const RowCols &a, const RowVals &v, const Tile &td, int sub, uint32_t *cnt) {
   RowSlice m;
-  m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.lc4 = 0;
+  m.src = nullptr; m.dst[0] = m.dst[1] = m.dst[2] = m.dst[3] = cnt; m.rot8 = 0; m.nd = 0; m.tl = -1; m.lc4 = 0; m.pick0 = 0x03020100u;
   m.mask_first = ~0u; m.mask_last = ~0u;
   if (v.ok) {
     // row index of the tile's first position; |rel| < Lmax + T for a candidate row
@@ -75,6 +77,7 @@ __device__ __forceinline__ RowSlice cx_slice_of(const RowCols &a, const RowVals 
       const int32_t e_lo = (int32_t)b0 & 3;              // slice bytes are e in [e_lo, e_hi) from the aligned start
       const int32_t e_hi = e_lo + (hi - lo);
       m.nd = (e_hi + 3) >> 2;
+      m.tl = m.nd - 1 - sub;
       m.src = reinterpret_cast<const uint32_t *>(a.xm + (b0 - e_lo)) + sub;
       // Bank-conflict-free LDS atomics: at sub-step j a lane adds at position d + 4*sub' + ((j+rot)&3), i.e. in
       // bank residue (d + j + rot) mod 4.  The 8 lanes of one "eighth" of a 32-lane half are 4 cells apart
@@ -87,6 +90,7 @@ __device__ __forceinline__ RowSlice cx_slice_of(const RowCols &a, const RowVals 
 #pragma unroll
       for (int j = 0; j < 4; j++) m.dst[j] = dst0 + ((j + rot) & 3);
       m.lc4 = v.ps == 0 ? 0x08080808u : 0u;
+      m.pick0 = v.ps == 0 ? 0x07060504u : 0x03020100u;
       m.mask_first = sub == 0 ? 0xFFFFFFFFu << (8 * e_lo) : ~0u;
       m.mask_last = 0xFFFFFFFFu >> (8 * (4 * m.nd - e_hi));
     }
@@ -105,15 +109,15 @@ __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &t
 // padding for that.  The byte order is rotated per lane (RowSlice::rot8) so that the 32 lanes of a half
 // wavefront always hit 32 different LDS banks.
 template <int T, int OFF, bool FIRST, bool PK = false>
-__device__ __forceinline__ void cx_add_dword(uint32_t w, int k, const RowSlice &m) {
-  const uint32_t c4 = (w & 0x0F0F0F0Fu) | m.lc4;         // four codes (unpack_ctx_idx | lower-case bit)
-  const uint32_t lo3 = c4 & 0x07070707u;
+__device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSlice &m) {
+  const uint32_t lo3 = w & 0x07070707u;                  // low three bits of the four codes (unpack_ctx_idx)
   // 16-entry byte LUT = two v_perm lookups (codes 0-7 / 8-15) + a third v_perm that picks, per byte,
-  // the second result when bit 3 of the code is set (selector j + 4*bit3): no multiply, no masks
-  const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
+  // the second result when bit 3 of the code is set or the read is lower-cased (selector j + 4*bit3):
+  // no multiply, no masks
+  const uint32_t pick = ((w >> 1) & 0x04040404u) | m.pick0;
   uint32_t s4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(PK ? kPkHi1 : kLutHi1, PK ? kPkHi0 : kLutHi0, lo3),
                                       __builtin_amdgcn_perm(PK ? kPkLo1 : kLutLo1, PK ? kPkLo0 : kLutLo0, lo3), pick);
-  uint32_t vm = k == m.nd - 1 ? m.mask_last : ~0u;
+  uint32_t vm = last ? m.mask_last : ~0u;
   if (FIRST) vm &= m.mask_first;
   s4 &= vm;
   s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
