@@ -42,8 +42,6 @@ struct CxArgs {
   uint32_t *cursor;                       // rows handed out so far (may exceed pool_cap: overflow)
   uint32_t *tile_nrow, *tile_base;
   int32_t *slab;                          // shared-tile counters [slot][16][T]
-  int pipe;                               // row steps in flight per wavefront (0: plain loop)
-  int64_t xm_bytes4;                      // bytes of xm rounded up to a dword (bound of the buffer loads of the pipelined variant)
   int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit, 4 loads only
   unsigned long long *diag;               // timing experiments only (EPIHIP_CX_DIAG): per-phase cycle sums of wave 0
   // ultra-deep tiles (amplicon pile-ups) are set aside by k_cx_tiles and split over many workgroups
@@ -56,9 +54,9 @@ struct CxArgs {
 
 // Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
 // (64/G rows per wavefront step); a lane keeps CX_NU dword loads of its row in flight and the next
-// step's row metadata is fetched before the current step's atomics are issued.  (A deeper software
-// pipeline -- bytes one step ahead, columns three -- measured slower: the kernel is issue-bound, not
-// latency-bound, once two workgroups share a CU.)
+// step's row columns are fetched with them.  (Deeper software pipelines -- bytes one step ahead and
+// columns three on the u32 layout, later two or three whole steps in flight through unconditional
+// buffer loads -- ran no faster: DESIGN.md 4.3.)
 // dwords u = U0..U1-1 of a lane's row slice (dword index sub + u*G), all already loaded
 template <int T, int G, int U0, int U1, bool PK>
 __device__ __forceinline__ void cx_add_range(const uint32_t (&w)[CX_NU], int sub, const RowSlice &cur) {
@@ -100,84 +98,6 @@ __device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, u
       cx_add_dword<T, 0, false, PK>(cur.src[k - sub], k == cur.nd - 1, t);
     }
     cur = nxt;
-  }
-}
-
-// Software-pipelined variant (D row steps of a wavefront in flight).  The plain loop above has a wave wait for its
-// bytes, count them, and only then ask for the next rows: with the counters taking 32 KiB of LDS per tile a CU holds
-// too few waves for the others to cover that wait (loads alone 0.64 ms, loads + counting 0.92 ms on 10 M templates).
-// Here step k's counting runs while the bytes of steps k+1..k+D-1 and the columns of steps k+D..k+2D-1 are on their
-// way.  Every load is issued on every path (row index clamped, bytes through a bounds-checked buffer descriptor
-// whose out-of-range lanes read 0 without touching memory), so the number of loads in flight is static and the
-// compiler waits with s_waitcnt vmcnt(N) for the oldest ones only, never vmcnt(0).
-__device__ __forceinline__ RowVals cx_load_row_clamped(const RowCols &a, const Tile &td, int r) {
-  RowVals v;
-  v.ok = r < td.row_hi;
-  const int rc = v.ok ? r : td.row_hi - 1;                // a tile has at least one candidate row
-  v.st = a.start[rc];
-  v.o = a.off[rc];
-  v.len = (int32_t)((uint32_t)a.off[rc + 1] - (uint32_t)v.o);
-  v.sd = a.strand[rc];
-  const int32_t *pp = a.pass ? a.pass : a.strand;         // one load either way
-  const int32_t ps = pp[rc];
-  v.ps = a.pass ? ps : 1;
-  return v;
-}
-
-template <int T, int G, int WG, bool PK, int D>
-__device__ __forceinline__ void cx_accumulate_pipe(const CxArgs &a, const Tile &td, uint32_t *cnt) {
-  constexpr int R = 64 / G;
-  constexpr int NW = WG / 64;
-  constexpr int STEP = NW * R;                            // rows the workgroup takes per step
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & (G - 1), grp = lane / G;
-  const int r0 = td.row_lo + wave * R + grp;
-  RowSlice S[D];
-  uint32_t W[D][CX_NU];
-  RowVals M[D];
-
-  // slice of the row in `v` + its CX_NU dword loads per lane, through a descriptor based at the wave's first row
-  // (offsets grow with the row index, so every lane's offset from it is >= 0 and, for a read shorter than 2^28
-  // bytes, < 2^32)
-  auto stage = [&](RowSlice &sl, uint32_t (&w)[CX_NU], const RowVals &v) {
-    sl = cx_slice_of<T, G, PK>(a.c, v, td, sub, cnt);
-    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)v.o) & ~3u;
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v.o >> 32));
-    const int64_t base = (int64_t)(((uint64_t)bhi << 32) | blo);
-    const int64_t left = a.xm_bytes4 - base;
-    const uint32_t nrec = left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)left;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.c.xm + base), 0, nrec, 0x00020000);
-    const uint32_t voff = sl.src ? (uint32_t)(reinterpret_cast<const uint8_t *>(sl.src) - (a.c.xm + base)) : 0xFFFFFFFFu;
-#pragma unroll
-    for (int u = 0; u < CX_NU; u++)
-      w[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + (uint32_t)(u * G * 4), 0, 0);
-  };
-
-  {
-    RowVals P[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) P[d] = cx_load_row_clamped(a.c, td, r0 + d * STEP);
-#pragma unroll
-    for (int d = 0; d < D; d++) M[d] = cx_load_row_clamped(a.c, td, r0 + (D + d) * STEP);
-#pragma unroll
-    for (int d = 0; d < D; d++) stage(S[d], W[d], P[d]);
-  }
-  int rm = r0 + 2 * D * STEP;                             // row whose columns are fetched next
-  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += D * STEP) {
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-      if (a.ablate & 4) {                                 // timing experiment: the loads without the counting
-        uint32_t x = 0;
-#pragma unroll
-        for (int u = 0; u < CX_NU; u++) x ^= W[d][u];
-        if (x == 0x12345678u && S[d].tl >= 0) atomicAdd(cnt, 1u);
-      } else {
-        cx_add_range<T, G, 0, CX_NU, PK>(W[d], sub, S[d]);
-      }
-      stage(S[d], W[d], M[d]);
-      M[d] = cx_load_row_clamped(a.c, td, rm);
-      rm += STEP;
-    }
   }
 }
 
@@ -295,7 +215,7 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
 
 // As many workgroups per CU as LDS and the 2048-thread limit allow (default: packed counters, 32 KiB, four
 // 512-thread workgroups); always 8 waves per SIMD, i.e. a VGPR budget of 64.
-template <int T, int G, int WG, bool PK, int D = 0>
+template <int T, int G, int WG, bool PK>
 __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_tiles(CxArgs a, int ntiles) {
   constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
@@ -321,10 +241,7 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
   for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (a.diag) t1 = __builtin_amdgcn_s_memtime();
-  if (!(a.ablate & 1)) {
-    if constexpr (D > 0) cx_accumulate_pipe<T, G, WG, PK, D>(a, td, cnt);
-    else cx_accumulate<T, G, WG, PK>(a, td, cnt);
-  }
+  if (!(a.ablate & 1)) cx_accumulate<T, G, WG, PK>(a, td, cnt);
   if (a.diag) t2 = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (a.diag) t3 = __builtin_amdgcn_s_memtime();
@@ -467,35 +384,9 @@ static int cx_workgroup_size() {
   return wg;
 }
 
-// EPIHIP_CX_PIPE=D: row steps a wavefront keeps in flight (cx_accumulate_pipe); 0 = the plain loop
-static int cx_pipe_depth() {
-  static int d = -1;
-  if (d < 0) {
-    d = 0;
-    if (const char *env = getenv("EPIHIP_CX_PIPE")) { const int v = atoi(env); if (v == 0 || v == 2 || v == 3) d = v; }
-  }
-  return d;
-}
-
-template <int T, int WG, bool PK, int D>
-static void launch_cx_tiles_pipe(int g, int nt, hipStream_t s, const CxArgs &a) {
-  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
-  switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG, PK, D>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG, PK, D>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, WG, PK, D>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, WG, PK, D>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-  }
-}
-
 template <int T, int WG, bool PK>
 static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
   const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
-  if constexpr (T == 1024 && PK && (WG == 256 || WG == 512)) {
-    const int d = a.pipe;
-    if (d == 2) { launch_cx_tiles_pipe<T, WG, PK, 2>(g, nt, s, a); return; }
-    if (d == 3) { launch_cx_tiles_pipe<T, WG, PK, 3>(g, nt, s, a); return; }
-  }
   switch (g) {
     case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
     case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
@@ -589,7 +480,6 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
   CxArgs a;
-  a.xm_bytes4 = (b->nbytes + 3) & ~(int64_t)3;
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = d_pass;
   a.tiles = b->tiles.as<Tile>();
   a.ctx_mask = ctx_mask;
@@ -599,12 +489,6 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.slab = b->d_slab;
   a.ablate = 0;
   if (const char *env = getenv("EPIHIP_CX_ABLATE")) a.ablate = atoi(env);
-  {
-    // the pipelined loop has no tail for slices longer than one round of loads, and its 32-bit buffer offsets
-    // span the rows of one wavefront step
-    const int slice_dw = ((st.max_len < T ? st.max_len : T) + 6) / 4;
-    a.pipe = (grp * CX_NU >= slice_dw && st.max_len < (1 << 28)) ? cx_pipe_depth() : 0;
-  }
   a.diag = nullptr;
   if (getenv("EPIHIP_CX_DIAG")) {
     EPI_TRY(b->diag.ensure(256));
