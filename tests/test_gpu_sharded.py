@@ -79,3 +79,64 @@ def test_sharded_equals_oracle(tmp_path, world, name):
         want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, 0, 0.1)
         got = dict(np.load(os.path.join(str(tmp_path), "%s_mhl%d.npz" % (name, hmax))))
         H.assert_reports_equal(got, want, float_cols=("length", "lmhl"))
+
+
+def _rccl_worker(rank, port, outdir):
+    """One rank on the real RCCL backend: the slab of a few tiles goes through all_reduce (an identity at world
+    size 1, but the same tensors, dtypes and stream hand-over as on a multi-GPU node) before the rows are emitted."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import epialleler_amd as ea
+    from epialleler_amd import distributed as D
+    t = _case("wgs")
+    shard = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"])
+    eng = D.HipShardEngine(shard)
+    first, last = eng.key_range()
+    mine = torch.tensor([first, last], dtype=torch.int64, device=dev)
+    allr = [torch.empty(2, dtype=torch.int64, device=dev)]
+    dist.all_gather(allr, mine)
+    assert tuple(allr[0].tolist()) == (first, last)
+    keys = np.array([k for k in range(first, first + 4) if (k >> 32) == (first >> 32) and k <= last], dtype=np.int64)
+    owned = np.ones(keys.size, dtype=np.int32)
+    c = H.CONTEXT_TO_BASES["CG"]
+    p = eng.threshold(c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+    slab = eng.cx_accumulate(p, c["ctx_meth"], keys, owned)
+    assert slab.is_cuda and slab.dtype == torch.int32 and slab.numel() > 0
+    before = slab.clone()
+    dist.all_reduce(slab, op=dist.ReduceOp.SUM)
+    assert torch.equal(before, slab)
+    cols = eng.cx_finish(c["ctx_meth"])
+    names = ("rname", "strand", "pos", "context", "meth", "unmeth")
+    np.savez(os.path.join(outdir, "rccl_cx.npz"), **{k: cols[i].cpu().numpy() for i, k in enumerate(names)})
+    mfirst, mlast = eng.key_range("mhl")
+    mkeys = np.array([k for k in range(mfirst, mfirst + 3) if (k >> 32) == (mfirst >> 32) and k <= mlast], dtype=np.int64)
+    cnt_slab, sum_slab = eng.mhl_accumulate("Zz", 0, 0, 0.1, mkeys, np.ones(mkeys.size, dtype=np.int32))
+    assert cnt_slab.dtype == torch.int32 and sum_slab.dtype == torch.int64 and sum_slab.is_cuda
+    dist.all_reduce(cnt_slab, op=dist.ReduceOp.SUM)
+    dist.all_reduce(sum_slab, op=dist.ReduceOp.SUM)
+    icols, dcols = eng.mhl_finish()
+    mn = ("rname", "strand", "pos", "context", "coverage", "length", "lmhl")
+    mc = [icols[i] for i in range(5)] + [dcols[i] for i in range(2)]
+    np.savez(os.path.join(outdir, "rccl_mhl.npz"), **{k: v.cpu().numpy() for k, v in zip(mn, mc)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_slab_roundtrip(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    t = _case("wgs")
+    c = H.CONTEXT_TO_BASES["CG"]
+    p = orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+    want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, "Z")
+    H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_cx.npz"))), want)
+    want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", 0, 0, 0.1)
+    H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_mhl.npz"))), want, float_cols=("length", "lmhl"))
