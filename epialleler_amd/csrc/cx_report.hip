@@ -39,7 +39,9 @@ struct CxArgs {
   uint32_t ctx_mask;                      // bit k set: context k (2,6,7) is reported
   uint32_t *pool_key, *pool_meth, *pool_unmeth;
   uint32_t pool_cap;
-  uint32_t *cursor;                       // rows handed out so far (may exceed pool_cap: overflow)
+  uint32_t *cursor;                       // rows handed out of the overflow region so far (may exceed its size)
+  uint32_t slot_rows, ovf_base;           // tile t owns pool rows [t * slot_rows, +slot_rows); larger tiles take
+                                          // rows from [ovf_base, pool_cap) through the cursor
   uint32_t *tile_nrow, *tile_base;
   int32_t *slab;                          // shared-tile counters [slot][16][T]
   int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit, 4 loads only
@@ -116,6 +118,17 @@ __device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, u
   return ((ctx_mask >> k) & 1u) ? k : 0;                  // :72
 }
 
+// Pool rows for a tile's n output rows.  Every tile has its own slot of slot_rows rows, so the common case needs no
+// atomic: one cursor for all tiles is ~10^5 atomics on one address, served one by one at ~8 ns each, and a workgroup
+// waited on its turn with 32 KiB of LDS in hand (0.13 ms of the 1.22 ms kernel on 10 M templates; with 512-position
+// tiles the cursor alone set the kernel time).  Only tiles with more rows than a slot go to the cursor.
+__device__ __forceinline__ uint32_t cx_pool_reserve(const CxArgs &a, int tile, uint32_t n, bool *fits) {
+  if (n <= a.slot_rows) { *fits = true; return (uint32_t)tile * a.slot_rows; }
+  const uint32_t o = atomicAdd(a.cursor, n);
+  *fits = (uint64_t)a.ovf_base + o + n <= a.pool_cap;
+  return a.ovf_base + o;
+}
+
 // Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
 template <int T, int WG, bool PK = false>
 __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
@@ -182,15 +195,17 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
     for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
     s_scan[NW] = acc;
     uint32_t base = 0;
-    if (acc) base = atomicAdd(a.cursor, acc);
+    bool fits = true;
+    if (acc) base = cx_pool_reserve(a, tile, acc, &fits);
     s_scan[NW + 1] = base;
+    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
     a.tile_nrow[tile] = acc;
     a.tile_base[tile] = base;
   }
   __syncthreads();
   const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
   const uint32_t ex = inc - (uint32_t)nr + s_scan[wave];
-  if ((uint64_t)base + total <= a.pool_cap) {
+  if (total != 0xFFFFFFFFu) {
     uint32_t w = base + ex;
 #pragma unroll
     for (int i = 0; i < 2 * PPT; i++) {
@@ -199,6 +214,96 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
         a.pool_meth[w] = me[i];
         a.pool_unmeth[w] = un[i];
         w++;
+      }
+    }
+  }
+}
+
+// Emit for the packed counters.  A wavefront owns T / (WG/64) consecutive positions and walks them in blocks of 32:
+// lanes 0-31 look at the '+' strand of the block, lanes 32-63 at the '-' strand (two conflict-free half-wave reads).
+// Pass 1 only asks whether any reported context has a count at all -- a row needs n_k > cov/2 >= 0 -- and writes
+// the (few) candidates, in key order, to a per-wave list; pass 2 reads the candidates densely, one per lane, and
+// applies the rule.  Ranks come from ballots and popcounts (no shuffle scan); a CG report evaluates the rule for
+// ~4 % of the (pos,strand) cells instead of all of them, a CX report for ~25 %.
+template <int T, int WG>
+__device__ __forceinline__ void cx_emit_packed(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan,
+                                               uint16_t *s_list) {
+  constexpr int NW = WG / 64, PW = T / NW, IT = PW / 32;
+  static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l5 = lane & 31, sd = lane >> 5;
+  const uint32_t below = (1u << l5) - 1u;
+  uint16_t *list = s_list + wave * (2 * PW);
+  const bool rH = (a.ctx_mask >> 2) & 1u, rX = (a.ctx_mask >> 6) & 1u, rZ = (a.ctx_mask >> 7) & 1u;
+  const uint32_t *cs = cnt + sd * 4 * T + wave * PW + l5;
+  uint32_t nc = 0;                                        // candidates of this wavefront (uniform)
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    uint32_t any = 0;
+    if (rH) any |= cs[1 * T + i * 32];
+    if (rX) any |= cs[2 * T + i * 32];
+    if (rZ) any |= cs[3 * T + i * 32];
+    const unsigned long long bal = __ballot(any != 0u);
+    const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
+    // key order inside a block: position first, '+' before '-': lane l precedes lane 32 + l
+    const uint32_t rank = (uint32_t)__popc(blo & below) + (uint32_t)__popc(bhi & below) + (sd ? (blo >> l5) & 1u : 0u);
+    if (any != 0u) list[nc + rank] = (uint16_t)(i * 64 + lane);
+    nc += (uint32_t)__popcll(bal);
+  }
+  uint32_t key[IT], me[IT], un[IT], off[IT];              // statically indexed (fully unrolled): stay in VGPRs
+  bool ok[IT];
+  uint32_t carry = 0;                                     // rows of this wavefront so far (uniform)
+#pragma unroll
+  for (int jj = 0; jj < IT; jj++) {
+    ok[jj] = false; key[jj] = 0; me[jj] = 0; un[jj] = 0; off[jj] = 0;
+    if ((uint32_t)(jj * 64) < nc) {
+      const uint32_t j = (uint32_t)(jj * 64 + lane);
+      bool good = false;
+      if (j < nc) {
+        const uint32_t id = list[j];
+        const int pos = wave * PW + (int)(id >> 6) * 32 + (int)(id & 31u), st = (int)((id >> 5) & 1u);
+        const uint32_t *c0 = cnt + st * 4 * T + pos;
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t w = c0[k * T]; c[2 * k] = w & 0xFFFFu; c[2 * k + 1] = w >> 16; }
+        uint32_t m = 0, u = 0;
+        const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
+        good = ctx != 0;
+        key[jj] = ((uint32_t)pos << 4) | ((uint32_t)st << 3) | (uint32_t)ctx;
+        me[jj] = m;
+        un[jj] = u;
+      }
+      const unsigned long long be = __ballot(good);
+      off[jj] = carry + __builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
+      carry += (uint32_t)__popcll(be);
+      ok[jj] = good;
+    }
+  }
+  if (lane == 0) s_scan[wave] = carry;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
+    s_scan[NW] = acc;
+    uint32_t base = 0;
+    bool fits = true;
+    if (acc) base = cx_pool_reserve(a, tile, acc, &fits);
+    s_scan[NW + 1] = base;
+    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
+    a.tile_nrow[tile] = acc;
+    a.tile_base[tile] = base;
+  }
+  __syncthreads();
+  const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
+  if (total != 0xFFFFFFFFu) {
+    const uint32_t w0 = base + s_scan[wave];
+#pragma unroll
+    for (int jj = 0; jj < IT; jj++) {
+      if (ok[jj]) {
+        const uint32_t w = w0 + off[jj];
+        a.pool_key[w] = key[jj];
+        a.pool_meth[w] = me[jj];
+        a.pool_unmeth[w] = un[jj];
       }
     }
   }
@@ -220,6 +325,7 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
   constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
   __shared__ uint32_t s_scan[WG / 64 + 2];
+  __shared__ uint16_t s_list[PK ? 2 * T : 2];              // candidate lists of the packed emit, 2 * T / (WG/64) per wavefront
   uint32_t *cnt = cnt_raw + kCxGuard;
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
@@ -252,7 +358,8 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
     return;
   }
   if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
-  cx_emit<T, WG, PK>(a, tile, cnt, s_scan);
+  if constexpr (PK) cx_emit_packed<T, WG>(a, tile, cnt, s_scan, s_list);
+  else cx_emit<T, WG, false>(a, tile, cnt, s_scan);
   if (a.diag && (threadIdx.x & 63) == 0) {      // diagnostic build only: where a wavefront's tile time goes
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
     const int w = threadIdx.x >> 6;
@@ -473,9 +580,22 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
-  // first call on this batch: room for a typical density of reported cytosines (CpG ~7 % of (pos,strand) pairs, all
-  // contexts ~50 %); an overflow is detected below and costs one rerun with the exact size
-  if (b->pool_cap == 0) EPI_TRY(ensure_pool(b, (size_t)nt * ((ctx_mask & ~(1u << 7)) ? (5 * T) / 4 : T / 4) + 65536));
+  // Row pool = one slot per tile + an overflow region behind the slots (cx_pool_reserve).  The slot size starts
+  // at a typical density of reported cytosines (CpG ~6 % of the (pos,strand) cells of a tile, all contexts ~40 %)
+  // and doubles for the next call when more than 1/8 of the rows went through the overflow cursor; an overflow of
+  // the region itself is detected below and costs one rerun with the exact size.
+  const int32_t nshared = (int32_t)b->shared_keys.size();
+  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * T : 0;   // shared tiles are emitted later into the same pool
+  uint32_t &slot_state = (ctx_mask & ~(1u << 7)) ? b->cx_slot_wide : b->cx_slot_cg;
+  if (!slot_state) slot_state = (ctx_mask & ~(1u << 7)) ? (uint32_t)(3 * T) / 4 : (uint32_t)T / 8;
+  uint32_t slot = slot_state > (uint32_t)(2 * T) ? (uint32_t)(2 * T) : slot_state;
+  if (const char *env = getenv("EPIHIP_CX_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }
+  while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
+  const size_t ovf_base = (size_t)nt * slot;
+  {
+    const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
+    if (b->pool_cap < ovf_base + ovf + headroom) EPI_TRY(ensure_pool(b, ovf_base + ovf + headroom));
+  }
   const int grp = pick_cx_group(st.max_len, T);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
@@ -504,10 +624,10 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.heavy_count = b->misc.as<uint32_t>() + 3;             // misc[3] = heavy tiles, misc[8] = their largest row count
   a.heavy_max = b->misc.as<uint32_t>() + 8;
   a.heavy_slab = nullptr;
-  const int32_t nshared = (int32_t)b->shared_keys.size();
-
-  // Shared tiles are emitted later (epi_batch_cx_finish_shared) into the same pool: keep room for them.
-  const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * T : 0;
+  a.slot_rows = slot;
+  a.ovf_base = (uint32_t)ovf_base;
+  b->cx_last_slot = slot;
+  b->cx_last_ovf = (uint32_t)ovf_base;
   uint32_t used_total[2] = {0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
@@ -541,9 +661,9 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     }
     used_total[0] = host[0];
     used_total[1] = host[1];
-    if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
+    if (ovf_base + used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once
+    EPI_TRY(ensure_pool(b, ovf_base + used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once
     if (nshared > 0)   // the rerun adds into the slab again
       EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * T * 4, s));
   }
@@ -556,6 +676,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
                 k ? "last" : "0", h[8 * k + 4], (double)h[8 * k] / h[8 * k + 4], (double)h[8 * k + 1] / h[8 * k + 4],
                 (double)h[8 * k + 2] / h[8 * k + 4], (double)h[8 * k + 3] / h[8 * k + 4]);
   }
+  if (used_total[0] > used_total[1] / 8 && slot_state < (uint32_t)(2 * T)) slot_state *= 2;   // too many tiles outgrew their slot
   if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
   b->last_kind = 1;
   b->last_nrow = used_total[1];
@@ -586,13 +707,15 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   a.pool_meth = b->pool_a.as<uint32_t>();
   a.pool_unmeth = b->pool_b.as<uint32_t>();
   a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
+  a.slot_rows = b->cx_last_slot;
+  a.ovf_base = b->cx_last_ovf;
   launch_cx_emit_slab(cx_tile_positions(), (int)b->shared_keys.size(), s, a, b->d_shared_owned.as<int32_t>(),
                       b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   {
     uint32_t used = 0;   // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
     EPI_TRY(read_scalars(b, s, cursor, 4, &used));
-    if (used > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
+    if ((size_t)a.ovf_base + used > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
   }
   uint32_t *d_total = b->misc.as<uint32_t>() + 2;
   EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));

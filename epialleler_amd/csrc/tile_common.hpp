@@ -147,7 +147,7 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSli
 template <int T, bool PK> constexpr int cx_lds_dwords() { return (PK ? 8 : kCxPlanes) * T; }
 // waves per SIMD the kernel is compiled for: as many workgroups per CU as LDS (160 KiB) and 2048 threads allow
 template <int T, int WG, bool PK> constexpr int cx_waves_per_simd() {
-  const int by_lds = (160 * 1024) / (cx_lds_dwords<T, PK>() * 4 + 256), by_thr = 2048 / WG;
+  const int by_lds = (160 * 1024) / (cx_lds_dwords<T, PK>() * 4 + 256 + (PK ? 4 * T : 0)), by_thr = 2048 / WG;   // + emit candidate lists
   const int wgs = by_lds < by_thr ? by_lds : by_thr;
   return wgs * WG / 256;
 }
