@@ -95,6 +95,7 @@ struct epi_batch {
   epi::DevBuf diag;                     // timing experiments only
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)
+  uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
   size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)
 

@@ -464,6 +464,7 @@ struct MhlArgs {
   uint32_t *pool_key, *pool_cov;
   unsigned long long *pool_hs, *pool_nu, *pool_de;   // sum h, sum S(M), sum S(h) of the row's (pos,strand)
   uint32_t pool_cap;
+  uint32_t slot_rows, ovf_base;          // a pool slot per tile, larger tiles behind them through the cursor (as in the CX report)
   uint32_t *cursor, *tile_nrow, *tile_base;
   // ultra-deep tiles are set aside and split over many workgroups (as in the CX kernel)
   int heavy_rows, heavy_chunk;
@@ -764,14 +765,23 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
     s_scan[NW] = acc;
     uint32_t base = 0;
-    if (acc) base = atomicAdd(a.cursor, acc);
+    bool fits = true;
+    if (acc) {
+      if (acc <= a.slot_rows) base = (uint32_t)tile * a.slot_rows;        // no atomic: see cx_pool_reserve (cx_report.hip)
+      else {
+        const uint32_t o = atomicAdd(a.cursor, acc);
+        fits = (uint64_t)a.ovf_base + o + acc <= a.pool_cap;
+        base = a.ovf_base + o;
+      }
+    }
     s_scan[NW + 1] = base;
+    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
     a.tile_nrow[tile] = acc;
     a.tile_base[tile] = base;
   }
   __syncthreads();
   const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
-  if ((uint64_t)base + total <= a.pool_cap) {
+  if (total != 0xFFFFFFFFu) {
     uint32_t w = base + inc - (uint32_t)nr + s_scan[wave];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -1074,7 +1084,6 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
-  if (mhl_pool_rows(b) == 0) EPI_TRY(ensure_mhl_pool(b, (size_t)nt * (kMhlTile / 4) + 65536));
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
 
   MhlArgs a;
@@ -1111,6 +1120,21 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   const int32_t nshared = (int32_t)b->shared_keys.size();
   if (nshared > 0 && (!a.shared_cnt || !a.shared_sums)) return fail(EPI_ERR_STATE, "shared tiles set without lMHL slabs (use epi_batch_mhl_set_shared)");
   const size_t headroom = nshared > 0 ? (size_t)nshared * 2 * MHL_T : 0;
+  // row pool = a slot per tile + an overflow region (see epi_batch_cx_report_dev): CpG haplotypes give ~7 % of the
+  // (pos,strand) cells of a tile a row; the slot doubles for the next call when 1/8 of the rows outgrew it
+  if (!b->mhl_slot) b->mhl_slot = MHL_T / 8;
+  uint32_t slot = b->mhl_slot > 2u * MHL_T ? 2u * MHL_T : b->mhl_slot;
+  if (const char *env = getenv("EPIHIP_MHL_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * MHL_T) slot = (uint32_t)v; }
+  while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
+  const size_t ovf_base = (size_t)nt * slot;
+  {
+    const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
+    if (mhl_pool_rows(b) < ovf_base + ovf + headroom) EPI_TRY(ensure_mhl_pool(b, ovf_base + ovf + headroom));
+  }
+  a.slot_rows = slot;
+  a.ovf_base = (uint32_t)ovf_base;
+  b->mhl_last_slot = slot;
+  b->mhl_last_ovf = (uint32_t)ovf_base;
   b->mhl_ctx_mask = ctx_mask;
   uint32_t used_total[2] = {0, 0};
   const int tg = pick_mhl_tile_group(st.max_len);
@@ -1207,14 +1231,15 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     }
     used_total[0] = host[0];
     used_total[1] = host[1];
-    if ((size_t)used_total[0] + headroom <= a.pool_cap) break;
+    if (ovf_base + used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 2) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_mhl_pool(b, (size_t)used_total[0] + (used_total[0] >> 4) + 1024 + headroom));
+    EPI_TRY(ensure_mhl_pool(b, ovf_base + used_total[0] + (used_total[0] >> 4) + 1024 + headroom));
     if (nshared > 0) {   // the rerun adds into the shared slabs again
       EPI_HIP(hipMemsetAsync(a.shared_cnt, 0, (size_t)nshared * 16 * MHL_T * 4, s));
       EPI_HIP(hipMemsetAsync(a.shared_sums, 0, (size_t)nshared * MHL_NSUM * 8, s));
     }
   }
+  if (used_total[0] > used_total[1] / 8 && b->mhl_slot < 2u * MHL_T) b->mhl_slot *= 2;   // too many tiles outgrew their slot
   if (nshared > 0) { b->last_kind = 4; return EPI_OK; }     // caller continues with epi_batch_mhl_finish_shared
   b->last_kind = 2;
   b->last_nrow = used_total[1];
@@ -1260,13 +1285,15 @@ int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out) {
   a.pool_nu = b->pool_e.as<unsigned long long>();
   a.pool_de = b->pool_f.as<unsigned long long>();
   a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
+  a.slot_rows = b->mhl_last_slot;
+  a.ovf_base = b->mhl_last_ovf;
   hipLaunchKernelGGL((k_mhl_emit_slab<MHL_WG>), dim3((unsigned)b->shared_keys.size()), dim3(MHL_WG), 0, s, a,
                      b->d_shared_owned.as<int32_t>(), b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
   uint32_t ut[2] = {0, 0};
   EPI_TRY(read_scalars(b, s, cursor, 8, ut));
-  if (ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded lMHL report");
+  if ((size_t)a.ovf_base + ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded lMHL report");
   b->last_kind = 2;
   b->last_nrow = ut[1];
   *nrow_out = ut[1];
