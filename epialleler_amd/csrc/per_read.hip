@@ -144,6 +144,183 @@ __global__ __launch_bounds__(256) void k_per_read(const uint8_t *__restrict__ xm
   }
 }
 
+// ---- wide layout -------------------------------------------------------------------------------------------------
+// The kernel above gives a read to 2 lanes, so one load instruction of a wavefront touches 32 reads x 32 bytes and
+// every 128-byte line is visited by four instructions: 3.9-4.5 TB/s.  Here 8 (or 16, 32, 64) lanes own a read and a
+// lane group works on RPG = 4 reads at once: an instruction covers 8 consecutive reads x 128 contiguous bytes, each
+// line is touched once, and with 3 loads x 4 reads in flight per lane the same bytes are on their way per wavefront
+// (scratch/ubench/row_loads.hip: 6.5 TB/s for this shape against 3.9 for the 2-lane one; a plain stream reads 6.4).
+// Class counting is cut to one LUT lookup per dword: the LUT byte holds the four class memberships as 2-bit fields
+// (a class string without repeated letters has weights 0/1), three dwords are added field-wise (<= 3), split into
+// even / odd fields of 4 bits and accumulated over the (at most three) 16-byte chunks of a lane: <= 12 per field.
+// Class strings with a repeated letter (weight 2+) and reads of 64 KiB or more take the kernel above.
+constexpr int PW_NU = 3;     // 16-byte loads per lane and read
+constexpr int PW_RPG = 4;    // reads per lane group
+
+__device__ __forceinline__ uint32_t pw_lut(uint32_t w, const ClassLut &F) {
+  const uint32_t lo3 = w & 0x07070707u;
+  const uint32_t pick = ((w >> 1) & 0x04040404u) | 0x03020100u;
+  return __builtin_amdgcn_perm(__builtin_amdgcn_perm(F.hi1, F.hi0, lo3), __builtin_amdgcn_perm(F.lo1, F.lo0, lo3), pick);
+}
+
+// sum over the G lanes of a group (G = 8, 16: DPP inside a row of 16 lanes; 32, 64: two more shuffles)
+template <int G>
+__device__ __forceinline__ uint32_t pw_group_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  if (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// bytes [lo,hi) of a dword set to 0xFF (32-bit arguments, any sign)
+__device__ __forceinline__ uint32_t byte_range_mask32(int lo, int hi) {
+  const int l = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+  const int h = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+  if (h <= l) return 0u;
+  const uint32_t mh = h == 4 ? ~0u : (1u << (8 * h)) - 1u;
+  const uint32_t ml = (1u << (8 * l)) - 1u;             // l < 4 here
+  return mh & ~ml;
+}
+
+// waves per SIMD the wide kernel is compiled for: the loads in flight take RPG * 12 VGPRs
+template <int RPG> constexpr int pw_waves() { return RPG >= 4 ? 5 : (RPG == 3 ? 6 : 8); }
+
+template <int G, int RPG, bool BETA>
+__global__ __launch_bounds__(256, (pw_waves<RPG>())) void k_per_read_wide(const uint8_t *__restrict__ xm, const int64_t *__restrict__ off,
+                                                                            int64_t n, ClassLut F, ThrParams prm,
+                                                                            int32_t *__restrict__ pass_out, double *__restrict__ beta_out) {
+  constexpr int RW = 64 / G;                            // lane groups per wavefront
+  const int sub = threadIdx.x & (G - 1);
+  const int g_in = (threadIdx.x & 63) / G;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row0 = wave * (RPG * RW) + g_in;        // reads row0 + q * RW: those of one instruction are consecutive
+  const uint8_t *base[RPG];                             // the read's first 16-byte chunk
+  int rel[RPG], len[RPG], nch[RPG];                     // first byte inside that chunk, length (< 65536), chunks
+#pragma unroll
+  for (int q = 0; q < RPG; q++) {
+    const int64_t row = row0 + (int64_t)q * RW;
+    const int64_t rc = row < n ? row : n - 1;           // every lane loads (the count of loads in flight stays static)
+    const int64_t o0 = off[rc], o1 = off[rc + 1];
+    rel[q] = (int)(o0 & 15);
+    len[q] = row < n ? (int)(o1 - o0) : 0;
+    nch[q] = len[q] > 0 ? (rel[q] + len[q] + 15) >> 4 : 0;
+    base[q] = nch[q] > 0 ? xm + (o0 & ~(int64_t)15) : xm;
+  }
+  // all loads are unconditional (chunk index clamped into the read): the compiler can then wait for the oldest
+  // ones with a counted vmcnt and start on read 0 while reads 1..RPG-1 are still on their way
+  uint4 w[RPG][PW_NU];
+#pragma unroll
+  for (int q = 0; q < RPG; q++) {
+    const int last = nch[q] > 0 ? nch[q] - 1 : 0;
+#pragma unroll
+    for (int u = 0; u < PW_NU; u++) {
+      const int k = sub + u * G;
+      w[q][u] = *reinterpret_cast<const uint4 *>(base[q] + ((int64_t)(k < last ? k : last) << 4));
+    }
+  }
+  uint32_t S01[RPG], S23[RPG];
+#pragma unroll
+  for (int q = 0; q < RPG; q++) {
+    uint32_t E = 0, O = 0;                              // 4-bit fields: classes 0, 2 (E) and 1, 3 (O) per byte lane
+    uint32_t cls[4] = {0, 0, 0, 0};
+    const int rs = rel[q], re = rel[q] + len[q];        // the read's bytes, counted from its first chunk
+    auto flush = [&]() {
+      cls[0] = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, cls[0]);
+      cls[2] = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, cls[2]);
+      cls[1] = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, cls[1]);
+      cls[3] = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, cls[3]);
+      E = 0; O = 0;
+    };
+    auto chunk = [&](const uint4 &v, int k) {
+#ifdef EPI_PW_NOALU
+      E ^= v.x ^ v.y ^ v.z ^ v.w;                         // timing experiment: loads only
+      return;
+#endif
+      const int g0 = k << 4;
+      uint32_t a = pw_lut(v.x, F), b = pw_lut(v.y, F), cc = pw_lut(v.z, F), d = pw_lut(v.w, F);
+      if (g0 < rs || g0 + 16 > re) {                    // first / last chunk of the read: mask foreign bytes
+        a &= byte_range_mask32(rs - g0, re - g0);
+        b &= byte_range_mask32(rs - g0 - 4, re - g0 - 4);
+        cc &= byte_range_mask32(rs - g0 - 8, re - g0 - 8);
+        d &= byte_range_mask32(rs - g0 - 12, re - g0 - 12);
+      }
+      const uint32_t t = a + b + cc;                    // 2-bit fields, <= 3
+      E += (t & 0x33333333u) + (d & 0x33333333u);       // 4-bit fields, += <= 4
+      O += ((t >> 2) & 0x33333333u) + ((d >> 2) & 0x33333333u);
+    };
+#pragma unroll
+    for (int u = 0; u < PW_NU; u++) {
+      const int k = sub + u * G;
+      if (k < nch[q]) chunk(w[q][u], k);
+    }
+    flush();
+    // reads longer than G * PW_NU chunks (the host picks G from the mean length): the rest, three chunks per flush
+    for (int kb = sub + PW_NU * G; kb < nch[q]; kb += PW_NU * G) {
+#pragma unroll
+      for (int u = 0; u < PW_NU; u++) {
+        const int k = kb + u * G;
+        if (k < nch[q]) chunk(*reinterpret_cast<const uint4 *>(base[q] + ((int64_t)k << 4)), k);
+      }
+      flush();
+    }
+    // a read is shorter than 64 KiB here: two counts per word through the group sum (every lane of the group gets it)
+    S01[q] = pw_group_sum<G>(cls[0] | (cls[1] << 16));
+    S23[q] = pw_group_sum<G>(cls[2] | (cls[3] << 16));
+  }
+  // one pass of comparisons and IEEE divisions for all RPG reads of the group: lane q of the group decides read q
+  uint32_t s01 = S01[0], s23 = S23[0];
+#pragma unroll
+  for (int q = 1; q < RPG; q++) {
+    if (sub == q) { s01 = S01[q]; s23 = S23[q]; }
+  }
+  const int64_t row = row0 + (int64_t)sub * RW;
+  if (sub < RPG && row < n) {
+    const unsigned n_m = s01 & 0xFFFFu, n_u = s01 >> 16;
+    if (BETA) {
+      unsigned n_all = n_m + n_u;                       // rcpp_get_xm_beta.cpp:37-39
+      if (n_all == 0) n_all = 1;
+      beta_out[row] = (double)n_m / (double)n_all;
+    } else {
+      int res = 0;                                      // rcpp_threshold_reads.cpp:43-70
+      if (n_m != 0) {
+        const unsigned n_all = n_m + n_u;
+        if (!(n_all < prm.min_n_ctx)) {
+          const double frac = (double)n_m / (double)n_all;
+          if (!(frac < prm.min_ctx_meth_frac)) {
+            res = 1;
+            const unsigned o_m = s23 & 0xFFFFu;
+            if (o_m > 0) {
+              const unsigned o_all = o_m + (s23 >> 16);
+              const double ofrac = (double)o_m / (double)o_all;
+              if (ofrac > prm.max_ooctx_meth_frac) res = 0;
+            }
+          }
+        }
+      }
+      pass_out[row] = res;
+    }
+  }
+}
+
+// 2-bit membership fields of up to four classes in one LUT; false when a class string repeats a letter
+static bool make_field_lut(const char *const cls[4], ClassLut *out) {
+  unsigned f[16] = {0};
+  for (int k = 0; k < 4; k++) {
+    unsigned w[16] = {0};
+    if (cls[k]) for (const unsigned char *c = reinterpret_cast<const unsigned char *>(cls[k]); *c; c++) w[ctx_to_idx(*c)]++;
+    for (int i = 0; i < 16; i++) {
+      if (w[i] > 1) return false;
+      f[i] |= w[i] << (2 * k);
+    }
+  }
+  auto pack = [&](int b) { return (uint32_t)(f[b] | (f[b + 1] << 8) | (f[b + 2] << 16) | (f[b + 3] << 24)); };
+  out->lo0 = pack(0); out->lo1 = pack(4); out->hi0 = pack(8); out->hi1 = pack(12);
+  return true;
+}
+
 static int pick_group(const epi_batch *b) {
   const char *env = getenv("EPIHIP_GROUP");
   if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
@@ -156,10 +333,43 @@ static int pick_group(const epi_batch *b) {
   return g;
 }
 
+// the wide kernel when the class strings allow it (F != nullptr) and no read reaches 64 KiB
+template <bool BETA>
+static int launch_per_read_wide(epi_batch *b, const ClassLut &F, const ThrParams &prm, int32_t *d_pass, double *d_beta,
+                                hipStream_t s) {
+  const int64_t mean = b->n > 0 ? b->nbytes / b->n : 0;
+  const int64_t chunks = mean / 16 + 2;
+  int g = 8;
+  while (g < 64 && (int64_t)g * PW_NU < chunks) g <<= 1;
+  static int rpg = 0;
+  if (!rpg) { rpg = PW_RPG; if (const char *env = getenv("EPIHIP_PR_RPG")) { const int v = atoi(env); if (v >= 2 && v <= 4) rpg = v; } }
+  const int64_t rows_per_wg = 4 * (int64_t)rpg * (64 / g);
+  const unsigned nb = (unsigned)((b->n + rows_per_wg - 1) / rows_per_wg);
+  const char *pname = BETA ? "xm_beta" : "threshold";
+  prof_begin(pname, s);
+#define EPI_PW(GG, RR) hipLaunchKernelGGL((k_per_read_wide<GG, RR, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->n, F, prm, d_pass, d_beta)
+#define EPI_PW_G(RR)                                                                   \
+  switch (g) { case 8: EPI_PW(8, RR); break; case 16: EPI_PW(16, RR); break; case 32: EPI_PW(32, RR); break; default: EPI_PW(64, RR); break; }
+  if (rpg == 2) { EPI_PW_G(2) } else if (rpg == 3) { EPI_PW_G(3) } else { EPI_PW_G(4) }
+#undef EPI_PW_G
+#undef EPI_PW
+  prof_end(pname, s);
+  EPI_HIP(hipGetLastError());
+  return EPI_OK;
+}
+
 template <int NCLS, bool BETA>
 static int launch_per_read(epi_batch *b, const Luts &L, const ThrParams &prm, int32_t *d_pass, double *d_beta,
-                           hipStream_t s) {
+                           hipStream_t s, const ClassLut *F = nullptr) {
   if (b->n == 0) return EPI_OK;
+  {
+    static int wide = -1;
+    if (wide < 0) { wide = 1; if (const char *env = getenv("EPIHIP_PR_WIDE")) wide = atoi(env) != 0; }
+    if (F && wide) {
+      EPI_TRY(fetch_row_stats(b, s));                     // the longest read (known since ingest)
+      if (!b->h_stats.bad_len && b->h_stats.max_len < 65536 && b->nbytes >= 16) return launch_per_read_wide<BETA>(b, *F, prm, d_pass, d_beta, s);
+    }
+  }
   const int g = pick_group(b);
   const int64_t threads = b->n * g;
   const unsigned nb = (unsigned)((threads + 255) / 256);
@@ -200,7 +410,10 @@ int epi_batch_threshold_reads_dev(epi_batch *b, const char *ctx_meth, const char
   EPI_TRY(make_lut(ooctx_meth, &L.c[2]));
   EPI_TRY(make_lut(ooctx_unmeth, &L.c[3]));
   ThrParams prm{min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac};
-  return launch_per_read<4, false>(b, L, prm, d_pass_out, nullptr, pick_stream(b, stream));
+  ClassLut F;
+  const char *const cls[4] = {ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth};
+  const bool fields = make_field_lut(cls, &F);
+  return launch_per_read<4, false>(b, L, prm, d_pass_out, nullptr, pick_stream(b, stream), fields ? &F : nullptr);
 }
 
 int epi_batch_get_xm_beta_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, double *d_beta_out,
@@ -214,7 +427,10 @@ int epi_batch_get_xm_beta_dev(epi_batch *b, const char *ctx_meth, const char *ct
   EPI_TRY(make_lut(ctx_meth, &L.c[0]));
   EPI_TRY(make_lut(ctx_unmeth, &L.c[1]));
   ThrParams prm{0, 0.0, 0.0};
-  return launch_per_read<2, true>(b, L, prm, nullptr, d_beta_out, pick_stream(b, stream));
+  ClassLut F;
+  const char *const cls[4] = {ctx_meth, ctx_unmeth, nullptr, nullptr};
+  const bool fields = make_field_lut(cls, &F);
+  return launch_per_read<2, true>(b, L, prm, nullptr, d_beta_out, pick_stream(b, stream), fields ? &F : nullptr);
 }
 
 }  // extern "C"

@@ -1,0 +1,78 @@
+// microbenchmark: how fast can fixed-length rows (300 B) be streamed with 16-byte loads, by lanes-per-row layout?
+//   A: 2 lanes per row, 10 loads per lane (32 rows per wave-instruction, 32 B contiguous per row)   -- k_per_read today
+//   B: 8 lanes per row, 3 loads per lane, 4 rows per lane group (8 rows per instruction, 128 B contiguous per row)
+//   C: 4 lanes per row, 5 loads per lane, 2 rows per lane group (16 rows per instruction, 64 B per row)
+//   D: plain copy-like stream (consecutive lanes consecutive 16 B), 10 loads per lane
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+constexpr int L = 300;
+__device__ __forceinline__ uint32_t fold(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+
+template <int G, int NU, int RPG>   // lanes per row, loads per lane per row, rows per lane group handled together
+__global__ __launch_bounds__(256) void k_rows(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & (G - 1));
+  const int64_t grp = gid / G;                      // lane group
+  constexpr int RW = 64 / G;                        // lane groups per wave
+  const int64_t wave = grp / RW, g_in = grp % RW;
+  uint32_t acc = 0;
+  uint4 w[RPG][NU];
+#pragma unroll
+  for (int q = 0; q < RPG; q++) {
+    const int64_t row = (wave * RPG + q) * RW + g_in;   // rows of one instruction are consecutive
+    const int64_t rs = row * L, re = rs + L;
+    const int64_t c0 = rs >> 4, c1 = (re + 15) >> 4;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int64_t c = c0 + sub + (int64_t)u * G;
+      w[q][u] = (row < n && c < c1) ? *reinterpret_cast<const uint4 *>(xm + (c << 4)) : make_uint4(0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPG; q++)
+#pragma unroll
+    for (int u = 0; u < NU; u++) acc ^= fold(w[q][u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_stream(const uint8_t *__restrict__ xm, int64_t nchunks, uint32_t *out) {
+  const int64_t base = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) * NU + (threadIdx.x & 63);
+  uint4 w[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) { const int64_t c = base + (int64_t)u * 64; w[u] = c < nchunks ? reinterpret_cast<const uint4 *>(xm)[c] : make_uint4(0, 0, 0, 0); }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < NU; u++) acc ^= fold(w[u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <class F> void timeit(const char *name, double bytes, F launch) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  launch(); launch();
+  hipEventRecord(a);
+  for (int i = 0; i < 10; i++) launch();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
+  printf("%-60s %7.3f ms  %6.2f TB/s\n", name, ms, bytes / ms / 1e9);
+}
+
+int main() {
+  const int64_t n = 10000000, bytes = n * L;
+  uint8_t *xm; uint32_t *out;
+  hipMalloc(&xm, bytes + 4096); hipMalloc(&out, 64);
+  hipMemset(xm, 0x5B, bytes + 4096);
+  auto grid = [&](int G, int RPG) { return (unsigned)((n / RPG * G + 255) / 256 + 64); };
+  timeit("A  2 lanes x 10 loads, 1 row  (32 rows/instr, 32 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<2, 10, 1>), dim3(grid(2, 1)), dim3(256), 0, 0, xm, n, out); });
+  timeit("B  8 lanes x 3 loads, 4 rows  (8 rows/instr, 128 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<8, 3, 4>), dim3(grid(8, 4)), dim3(256), 0, 0, xm, n, out); });
+  timeit("B2 8 lanes x 3 loads, 3 rows", bytes, [&] { hipLaunchKernelGGL((k_rows<8, 3, 3>), dim3(grid(8, 3)), dim3(256), 0, 0, xm, n, out); });
+  timeit("C  4 lanes x 5 loads, 2 rows  (16 rows/instr, 64 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<4, 5, 2>), dim3(grid(4, 2)), dim3(256), 0, 0, xm, n, out); });
+  timeit("C2 4 lanes x 5 loads, 3 rows", bytes, [&] { hipLaunchKernelGGL((k_rows<4, 5, 3>), dim3(grid(4, 3)), dim3(256), 0, 0, xm, n, out); });
+  timeit("E  2 lanes x 10 loads, 2 rows (20 loads in flight)", bytes, [&] { hipLaunchKernelGGL((k_rows<2, 10, 2>), dim3(grid(2, 2)), dim3(256), 0, 0, xm, n, out); });
+  timeit("F  16 lanes x 2 loads, 6 rows (4 rows/instr, 256 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<16, 2, 6>), dim3(grid(16, 6)), dim3(256), 0, 0, xm, n, out); });
+  const int64_t nch = bytes / 16;
+  timeit("D  plain stream, 10 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<10>), dim3((unsigned)((nch / 10 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
+  timeit("D4 plain stream, 4 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<4>), dim3((unsigned)((nch / 4 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
+  return 0;
+}

@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_CX_GROUP": "16", "EPIHIP_HEAVY_ROWS": "500"},
     {"EPIHIP_CX_PACKED": "0", "EPIHIP_CX_GROUP": "64", "EPIHIP_HEAVY_ROWS": "500"},
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot
+    {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
     {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL: nearly every tile outgrows its pool slot
     {"EPIHIP_MHL_SLOT": "0"},
