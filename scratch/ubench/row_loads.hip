@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <string.h>
 constexpr int L = 300;
 __device__ __forceinline__ uint32_t fold(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
 
@@ -33,6 +34,28 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t *__restrict__ xm, in
   for (int q = 0; q < RPG; q++)
 #pragma unroll
     for (int u = 0; u < NU; u++) acc ^= fold(w[q][u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+// the CX tile kernel's shape: G lanes per row, NU dword (4-byte) or 8-byte loads per lane, 64/G rows per instruction
+template <int G, int NU, class V>
+__global__ __launch_bounds__(256) void k_rows_small(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & (G - 1));
+  const int64_t row = gid / G;
+  const int64_t rs = row * L, re = rs + L;
+  constexpr int B = sizeof(V);
+  const int64_t c0 = rs / B, c1 = (re + B - 1) / B;
+  V w[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int64_t c = c0 + sub + (int64_t)u * G;
+    V z; memset(&z, 0, sizeof(z));
+    w[u] = (row < n && c < c1) ? *reinterpret_cast<const V *>(xm + c * B) : z;
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < NU; u++) { const uint32_t *p = reinterpret_cast<const uint32_t *>(&w[u]); for (int i = 0; i < B / 4; i++) acc ^= p[i]; }
   if (acc == 0x12345678u) out[0] = acc;
 }
 
@@ -71,6 +94,10 @@ int main() {
   timeit("C2 4 lanes x 5 loads, 3 rows", bytes, [&] { hipLaunchKernelGGL((k_rows<4, 5, 3>), dim3(grid(4, 3)), dim3(256), 0, 0, xm, n, out); });
   timeit("E  2 lanes x 10 loads, 2 rows (20 loads in flight)", bytes, [&] { hipLaunchKernelGGL((k_rows<2, 10, 2>), dim3(grid(2, 2)), dim3(256), 0, 0, xm, n, out); });
   timeit("F  16 lanes x 2 loads, 6 rows (4 rows/instr, 256 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<16, 2, 6>), dim3(grid(16, 6)), dim3(256), 0, 0, xm, n, out); });
+  timeit("G  8 lanes x 10 dword loads  (8 rows/instr, 32 B each: CX tile kernel)", bytes, [&] { hipLaunchKernelGGL((k_rows_small<8, 10, uint32_t>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("H  8 lanes x 5 8-byte loads  (8 rows/instr, 64 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows_small<8, 5, uint2>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("I  4 lanes x 10 8-byte loads (16 rows/instr, 32 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows_small<4, 10, uint2>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("J  8 lanes x 3 16-byte loads, 1 row (8 rows/instr, 128 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<8, 3, 1>), dim3(grid(8, 1)), dim3(256), 0, 0, xm, n, out); });
   const int64_t nch = bytes / 16;
   timeit("D  plain stream, 10 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<10>), dim3((unsigned)((nch / 10 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
   timeit("D4 plain stream, 4 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<4>), dim3((unsigned)((nch / 4 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
