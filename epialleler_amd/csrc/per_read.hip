@@ -163,12 +163,12 @@ __device__ __forceinline__ uint32_t pw_lut(uint32_t w, const ClassLut &F) {
   return __builtin_amdgcn_perm(__builtin_amdgcn_perm(F.hi1, F.hi0, lo3), __builtin_amdgcn_perm(F.lo1, F.lo0, lo3), pick);
 }
 
-// sum over the G lanes of a group (G = 8, 16: DPP inside a row of 16 lanes; 32, 64: two more shuffles)
+// sum over the G lanes of a group (G <= 16: DPP inside a row of 16 lanes; 32, 64: two more shuffles)
 template <int G>
 __device__ __forceinline__ uint32_t pw_group_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  if (G >= 4) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  if (G >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
   if (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
   if (G >= 32) v += __shfl_xor(v, 16, 64);
   if (G >= 64) v += __shfl_xor(v, 32, 64);
@@ -339,10 +339,11 @@ static int launch_per_read_wide(epi_batch *b, const ClassLut &F, const ThrParams
                                 hipStream_t s) {
   const int64_t mean = b->n > 0 ? b->nbytes / b->n : 0;
   const int64_t chunks = mean / 16 + 2;
-  int g = 8;
+  int g = 2;                                              // short reads: fewer lanes per read (a 50-byte read is 4-5 chunks)
   while (g < 64 && (int64_t)g * PW_NU < chunks) g <<= 1;
-  static int rpg = 0;
-  if (!rpg) { rpg = PW_RPG; if (const char *env = getenv("EPIHIP_PR_RPG")) { const int v = atoi(env); if (v >= 2 && v <= 4) rpg = v; } }
+  static int rpg_env = 0;
+  if (!rpg_env) { rpg_env = PW_RPG; if (const char *env = getenv("EPIHIP_PR_RPG")) { const int v = atoi(env); if (v >= 2 && v <= 4) rpg_env = v; } }
+  const int rpg = g == 2 ? 2 : (g == 4 ? 4 : rpg_env);    // lane q of a group decides read q: RPG <= G
   const int64_t rows_per_wg = 4 * (int64_t)rpg * (64 / g);
   const unsigned nb = (unsigned)((b->n + rows_per_wg - 1) / rows_per_wg);
   const char *pname = BETA ? "xm_beta" : "threshold";
@@ -350,7 +351,9 @@ static int launch_per_read_wide(epi_batch *b, const ClassLut &F, const ThrParams
 #define EPI_PW(GG, RR) hipLaunchKernelGGL((k_per_read_wide<GG, RR, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->n, F, prm, d_pass, d_beta)
 #define EPI_PW_G(RR)                                                                   \
   switch (g) { case 8: EPI_PW(8, RR); break; case 16: EPI_PW(16, RR); break; case 32: EPI_PW(32, RR); break; default: EPI_PW(64, RR); break; }
-  if (rpg == 2) { EPI_PW_G(2) } else if (rpg == 3) { EPI_PW_G(3) } else { EPI_PW_G(4) }
+  if (g == 2) EPI_PW(2, 2);
+  else if (g == 4) EPI_PW(4, 4);
+  else if (rpg == 2) { EPI_PW_G(2) } else if (rpg == 3) { EPI_PW_G(3) } else { EPI_PW_G(4) }
 #undef EPI_PW_G
 #undef EPI_PW
   prof_end(pname, s);
