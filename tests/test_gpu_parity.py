@@ -146,6 +146,32 @@ def test_ragged_random(ea):
         check_all(ea, synth_np.random_templates(rng, n, 0, mx, 3, span))
 
 
+@pytest.mark.parametrize("mean_len", [20, 100, 250, 600, 1300, 4000])
+def test_per_read_kernels_every_group_size(ea, mean_len):
+    """The wide per-read kernel picks 2..64 lanes per read from the mean read length; ragged lengths up to 2.5x the mean
+    make some reads longer than one round of a group's loads (the tail loop) and some empty."""
+    rng = np.random.default_rng(mean_len)
+    n = max(200, 400000 // mean_len)
+    t = synth_np.random_templates(rng, n, 0, int(2.5 * mean_len), 2, 50000, p_garbage=0.02)
+    bam = pb(ea, t)
+    try:
+        for ctx in ("CG", "CHG", "CHH", "CxG", "CX"):
+            c = C2B[ctx]
+            for min_n, min_beta, max_oo in ((2, 0.5, 0.1), (1, 0.0, 1.0), (5, 0.9, 0.0)):
+                got = ea.rcpp_threshold_reads(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], min_n, min_beta, max_oo)
+                want = o_thr(t, ctx, min_n, min_beta, max_oo)
+                assert np.array_equal(got.astype(np.int32), want), ("threshold", ctx, min_n)
+            gb = ea.rcpp_get_xm_beta(bam, c["ctx_meth"], c["ctx_unmeth"])
+            wb = orc.get_xm_beta(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"])
+            assert np.array_equal(gb.view(np.uint64), wb.view(np.uint64)), ("beta", ctx)
+        # a class string with a repeated letter (weight 2) takes the general kernel
+        got = ea.rcpp_threshold_reads(bam, "ZZ", "z", "XH", "xh", 2, 0.5, 0.1)
+        want = orc.threshold_reads(t["xm"], t["off"], "ZZ", "z", "XH", "xh", 2, 0.5, 0.1)
+        assert np.array_equal(got.astype(np.int32), want)
+    finally:
+        bam.close()
+
+
 def test_tile_boundaries_and_large_positions(ea):
     rng = np.random.default_rng(5)
     # starts straddling multiples of the tile sizes (512/1024), near 2^31, and at position 0/1
