@@ -129,8 +129,8 @@ __device__ __forceinline__ uint32_t cx_pool_reserve(const CxArgs &a, int tile, u
   return a.ovf_base + o;
 }
 
-// Rule + ordered compaction of one tile's counters (LDS or staged from the slab) into the row pool.
-template <int T, int WG, bool PK = false>
+// Rule + ordered compaction of one tile's u32 counters [16][T] (LDS, or staged from a slab) into the row pool.
+template <int T, int WG>
 __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
   constexpr int PPT = T / WG;                          // consecutive positions per thread
   static_assert(PPT == 1 || PPT == 2 || PPT == 4, "emit phase layout");
@@ -145,35 +145,10 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       uint32_t c[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
       uint32_t m = 0, u = 0;
-      int ctx = 0;
-      if constexpr (PK) {
-        // a row needs n_k > cov/2 >= 0 for a reported context k: when the pairs of all reported contexts are
-        // empty (most positions of a CG report) the other counters are not even read
-        uint32_t w[4];
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 1; k < 4; k++) {
-          constexpr int kCtxOfPair[4] = {0, 2, 6, 7};
-          w[k] = 0;
-          if ((a.ctx_mask >> kCtxOfPair[k]) & 1u) { w[k] = cnt[(s * 4 + k) * T + p0 + q]; any |= w[k]; }
-        }
-        if (any) {
-#pragma unroll
-          for (int k = 1; k < 4; k++) {
-            constexpr int kCtxOfPair[4] = {0, 2, 6, 7};
-            if (!((a.ctx_mask >> kCtxOfPair[k]) & 1u)) w[k] = cnt[(s * 4 + k) * T + p0 + q];
-          }
-          w[0] = cnt[(s * 4) * T + p0 + q];
-#pragma unroll
-          for (int k = 0; k < 4; k++) { c[2 * k] = w[k] & 0xFFFFu; c[2 * k + 1] = w[k] >> 16; }
-          ctx = cx_rule(c, a.ctx_mask, &m, &u);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
-        ctx = cx_rule(c, a.ctx_mask, &m, &u);
-      }
+      const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
       ok[q * 2 + s] = ctx != 0;
       key[q * 2 + s] = ((uint32_t)(p0 + q) << 4) | ((uint32_t)s << 3) | (uint32_t)ctx;
       me[q * 2 + s] = m;
@@ -359,7 +334,7 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
   }
   if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   if constexpr (PK) cx_emit_packed<T, WG>(a, tile, cnt, s_scan, s_list);
-  else cx_emit<T, WG, false>(a, tile, cnt, s_scan);
+  else cx_emit<T, WG>(a, tile, cnt, s_scan);
   if (a.diag && (threadIdx.x & 63) == 0) {      // diagnostic build only: where a wavefront's tile time goes
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
     const int w = threadIdx.x >> 6;
