@@ -306,7 +306,9 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
   if (tile >= ntiles) return;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
   if (a.diag) t0 = __builtin_amdgcn_s_memtime();
-  const Tile td = a.tiles[tile];
+  const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
+  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
     if (threadIdx.x == 0) {
@@ -318,8 +320,6 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
     }
     return;
   }
-  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (a.diag) t1 = __builtin_amdgcn_s_memtime();
   if (!(a.ablate & 1)) cx_accumulate<T, G, WG, PK>(a, td, cnt);

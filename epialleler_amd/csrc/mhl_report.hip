@@ -828,7 +828,14 @@ __global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_tiles(Mh
   const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
-  const Tile td = a.tiles[tile];
+  const Tile td = a.tiles[tile];                         // (in flight while LDS is cleared, 16 bytes per store)
+  static_assert(MHL_LDS_CNT % 4 == 0 && (MHL_NSUM * sizeof(ST)) % 16 == 0, "LDS is cleared in 16-byte pieces");
+  {
+    uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+    for (int i = threadIdx.x; i < MHL_LDS_CNT / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+    uint4 *zs = reinterpret_cast<uint4 *>(sums);
+    for (int i = threadIdx.x; i < (int)(MHL_NSUM * sizeof(ST) / 16); i += WG) zs[i] = make_uint4(0, 0, 0, 0);
+  }
   if (td.row_hi - td.row_lo > a.heavy_rows) {            // pile-up: k_mhl_heavy splits it by row chunks
     if (threadIdx.x == 0) {
       const uint32_t h = atomicAdd(a.heavy_count, 1u);
@@ -839,8 +846,6 @@ __global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_tiles(Mh
     }
     return;
   }
-  for (int i = threadIdx.x; i < MHL_LDS_CNT; i += WG) cnt_raw[i] = 0;
-  for (int i = threadIdx.x; i < MHL_NSUM; i += WG) sums[i] = (ST)0;
   __syncthreads();
   mhl_accumulate<G, WG>(a, td, L);
   __syncthreads();
