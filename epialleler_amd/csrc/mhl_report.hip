@@ -752,13 +752,11 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     de[s] = L.sums[MHL_DD + s * MHL_SLEN + mhl_pad(p)];                      // :93 denominator
     nr += k != 0;
   }
-  uint32_t inc = (uint32_t)nr;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
-  if (lane == 63) s_scan[wave] = inc;
+  // rows of the lower lanes from two ballots (a lane has 0..2 rows: one per strand), no shuffle scan
+  const unsigned long long b0 = __ballot(ok[0]), b1 = __ballot(ok[1]);
+  const uint32_t inc = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                       __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) + (uint32_t)nr;
+  if (lane == 0) s_scan[wave] = (uint32_t)(__popcll(b0) + __popcll(b1));
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
