@@ -681,9 +681,25 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
 
 // Rule, prefix sums of the difference arrays, ordered compaction of one tile (one position per thread).  The pool rows
 // carry the three integer sums; the two divisions (:92-93) are done by k_mhl_gather, one row per lane.
-__device__ __forceinline__ uint32_t mhl_shfl_up(uint32_t v, int d) { return __shfl_up(v, d, 64); }
-__device__ __forceinline__ unsigned long long mhl_shfl_up(unsigned long long v, int d) {
-  return ((unsigned long long)__shfl_up((uint32_t)(v >> 32), d, 64) << 32) | __shfl_up((uint32_t)v, d, 64);
+// inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1, 2, 4, 8 inside a row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): no LDS traffic, unlike __shfl_up (ds_bpermute)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t mhl_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);   // lanes without a source get 0
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long mhl_dpp(unsigned long long v) {
+  return ((unsigned long long)mhl_dpp<CTRL, ROWS>((uint32_t)(v >> 32)) << 32) | mhl_dpp<CTRL, ROWS>((uint32_t)v);
+}
+template <class ST>
+__device__ __forceinline__ ST mhl_wave_scan(ST v) {
+  v += mhl_dpp<0x111, 0xF>(v);
+  v += mhl_dpp<0x112, 0xF>(v);
+  v += mhl_dpp<0x114, 0xF>(v);
+  v += mhl_dpp<0x118, 0xF>(v);
+  v += mhl_dpp<0x142, 0xA>(v);
+  v += mhl_dpp<0x143, 0xC>(v);
+  return v;
 }
 
 template <int WG, bool PK, class ST>
@@ -704,12 +720,7 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     for (int j = 0; j < PER; j++) x[j] = arr[j];
 #pragma unroll
     for (int j = 1; j < PER; j++) x[j] += x[j - 1];
-    ST inc = x[PER - 1];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const ST t = mhl_shfl_up(inc, d);
-      if (lane >= d) inc += t;
-    }
+    const ST inc = mhl_wave_scan<ST>(x[PER - 1]);
     const ST ex = inc - x[PER - 1];
 #pragma unroll
     for (int j = 0; j < PER; j++) arr[j] = x[j] + ex;
