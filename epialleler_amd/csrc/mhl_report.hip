@@ -263,6 +263,72 @@ __device__ __forceinline__ bool mhl_keep(uint32_t h, uint32_t oo_m, uint32_t oo_
   return !((int)h < hmin || frac > max_oo);                                // :179
 }
 
+// Lane exchanges inside a group of G lanes as DPP moves where the distance allows (inside a row of 16 lanes): a
+// __shfl_* is a ds_bpermute through the LDS pipe with ~100 cycles of latency, and pass 1 chains about 35 of them per
+// wavefront.  A lane whose partner lies outside its group gets another group's value (or 0): callers mask those lanes.
+template <int CTRL>
+__device__ __forceinline__ uint32_t lane_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+// (row shifts do not cross the rows of 16 lanes: groups of 32 or 64 lanes keep the shuffles)
+template <int G, int D>
+__device__ __forceinline__ uint32_t grp_up(uint32_t v) {             // value of lane - D
+  if constexpr (G > 16) return __shfl_up(v, D, 64);
+  else if constexpr (D == 1) return lane_dpp<0x111>(v);
+  else if constexpr (D == 2) return lane_dpp<0x112>(v);
+  else if constexpr (D == 4) return lane_dpp<0x114>(v);
+  else return lane_dpp<0x118>(v);
+}
+template <int G, int D>
+__device__ __forceinline__ uint32_t grp_down(uint32_t v) {           // value of lane + D
+  if constexpr (G > 16) return __shfl_down(v, D, 64);
+  else if constexpr (D == 1) return lane_dpp<0x101>(v);
+  else if constexpr (D == 2) return lane_dpp<0x102>(v);
+  else if constexpr (D == 4) return lane_dpp<0x104>(v);
+  else return lane_dpp<0x108>(v);
+}
+// partner for a butterfly reduction over a group, applied for D = G/2 ... 1: quad_perm for 1 and 2, row_half_mirror
+// (i <-> 7-i) for 4 and row_mirror (i <-> 15-i) for 8 pair up the same partial sums as lane ^ D would
+template <int D>
+__device__ __forceinline__ uint32_t grp_bfly(uint32_t v) {
+  if constexpr (D == 1) return lane_dpp<0xB1>(v);
+  else if constexpr (D == 2) return lane_dpp<0x4E>(v);
+  else if constexpr (D == 4) return lane_dpp<0x141>(v);
+  else if constexpr (D == 8) return lane_dpp<0x140>(v);
+  else return __shfl_xor(v, D, 64);
+}
+// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into 2 and 3)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+
+// segmented scans over the G lanes of a read: members of the open segment to the left (pf) / right (sf) of a lane
+template <int G, int D>
+__device__ __forceinline__ void seg_scan_steps(Seg &pf, Seg &sf, int sub) {
+  if constexpr (D < G) {
+    Seg l, r;
+    l.has = grp_up<G, D>(pf.has); l.cnt = grp_up<G, D>(pf.cnt);
+    if (sub >= D) pf = seg_combine(l, pf);
+    r.has = grp_down<G, D>(sf.has); r.cnt = grp_down<G, D>(sf.cnt);
+    if (sub + D < G) sf = seg_combine(r, sf);            // walking leftwards: `r` was seen first
+    seg_scan_steps<G, D * 2>(pf, sf, sub);
+  }
+}
+template <int D>
+__device__ __forceinline__ uint32_t grp_sum(uint32_t v) {            // over the 2*D lanes of a group, every lane gets it
+  if constexpr (D >= 1) { v += grp_bfly<D>(v); return grp_sum<D / 2>(v); }
+  else return v;
+}
+template <int D>
+__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
+  if constexpr (D >= 1) { v |= grp_bfly<D>(v); return grp_or<D / 2>(v); }
+  else return v;
+}
+
 // Reads that fit one block of G lanes x 16*C bytes (every read of a short-read batch): 256/G reads per workgroup.
 template <int G, int C>
 __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
@@ -280,25 +346,12 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
 
   // members of the open segment to the left (enter) and to the right (cont) of this lane
   Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
-#pragma unroll
-  for (int d = 1; d < G; d <<= 1) {
-    Seg l, r;
-    l.has = __shfl_up(pf.has, d, G); l.cnt = __shfl_up(pf.cnt, d, G);
-    if (sub >= d) pf = seg_combine(l, pf);
-    r.has = __shfl_down(sf.has, d, G); r.cnt = __shfl_down(sf.cnt, d, G);
-    if (sub + d < G) sf = seg_combine(r, sf);                // walking leftwards: `r` was seen first
-  }
-  uint32_t enter = __shfl_up(pf.cnt, 1, G), cont = __shfl_down(sf.cnt, 1, G);
+  seg_scan_steps<G, 1>(pf, sf, sub);
+  uint32_t enter = grp_up<G, 1>(pf.cnt), cont = grp_down<G, 1>(sf.cnt);
   if (sub == 0) enter = 0u;
   if (sub == G - 1) cont = 0u;
-  uint32_t h = (uint32_t)bm_popc(c.U | c.L), oo_m = c.oom, oo_u = c.oou, anyk = c.K ? 1u : 0u;
-#pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) {
-    h += __shfl_xor(h, d, 64);
-    oo_m += __shfl_xor(oo_m, d, 64);
-    oo_u += __shfl_xor(oo_u, d, 64);
-    anyk |= __shfl_xor(anyk, d, 64);
-  }
+  const uint32_t h = grp_sum<G / 2>((uint32_t)bm_popc(c.U | c.L)), oo_m = grp_sum<G / 2>(c.oom), oo_u = grp_sum<G / 2>(c.oou);
+  const uint32_t anyk = grp_or<G / 2>(c.K ? 1u : 0u);
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   // the current maximum is read from L2 (an L1 copy would stay 0 and every read would issue the atomic: 67 ms)
   if (keep && sub == 0 && !(a.ablate & 8) && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
@@ -307,12 +360,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   const uint32_t nrec = run_count(P) + run_count(Q);
 
   // record slots: exclusive scan over the workgroup, one cursor atomic per workgroup
-  uint32_t inc = nrec;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
+  const uint32_t inc = wave_scan_u32(nrec);
   if (lane == 63) s_w[wave] = inc;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -326,9 +374,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   __syncthreads();
   const uint32_t base = s_w[4];
   const uint32_t my = base + s_w[wave] + inc - nrec;
-  uint32_t row_n = nrec;
-#pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) row_n += __shfl_xor(row_n, d, 64);
+  const uint32_t row_n = grp_sum<G / 2>(nrec);
   if (valid && sub == 0)
     a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, (int32_t)my, base == 0xFFFFFFFFu ? 0 : (int32_t)row_n);
   if (nrec && base != 0xFFFFFFFFu && !(a.ablate & 2)) {
