@@ -1,7 +1,8 @@
 #!/bin/bash
+# k_mhl_rows timing builds: EPIHIP_MHL_ABLATE bits 8 no cursor atomic, 9 no record writes, 10 no span bits, 11 no max_h atomic
 cd $GRAFT_REPO_ROOT
-run() { timeout -k 10 280 python bench.py --workload cfg4 --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/b_ra.log 2>&1; tail -1 gpurun_out/b_ra.log | python -c "
+for ab in 0 256 512 1024 2048 3840; do
+  EPIHIP_MHL_ABLATE=$ab timeout -k 10 200 python bench.py --workload cfg4 --steps 3 --warmup 1 --cpu-sample 0 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$1', d['roofline']['kernel_ms_all'])"; }
-run base
-EPIHIP_MHL_ABLATE=2048 EPIHIP_MHL_SUMS=64 run nomaxh
+d=json.loads(sys.stdin.read()); print('ablate=$ab', d['ms_per_step'], d['roofline']['kernel_ms_all'])" || exit 1
+done
