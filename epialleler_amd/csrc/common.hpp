@@ -139,6 +139,24 @@ void prof_begin(const char *name, hipStream_t s);
 void prof_end(const char *name, hipStream_t s);
 
 // context-string helpers (host)
+// Wave-level scans and reductions as DPP moves (row_shr 1, 2, 4, 8 inside a row of 16 lanes, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3): VALU instructions, where __shfl_* is a ds_bpermute through the
+// LDS pipe with ~100 cycles of latency.  Device code only.
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {      // inclusive prefix sum over the 64 lanes
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {       // sum over the 64 lanes (uniform result)
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(v), 63);
+}
+#endif
+
 inline unsigned ctx_to_idx(unsigned char c) { return ((unsigned(c) + 2u) >> 2) & 15u; }   // src/epialleleR.h:28
 
 }  // namespace epi

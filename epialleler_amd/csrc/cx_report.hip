@@ -157,12 +157,7 @@ __device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_
     }
   }
   // block-wide exclusive scan of nr
-  uint32_t inc = (uint32_t)nr;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
+  const uint32_t inc = wave_scan_u32((uint32_t)nr);
   if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
   if (threadIdx.x == 0) {

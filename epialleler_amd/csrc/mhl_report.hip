@@ -295,16 +295,6 @@ __device__ __forceinline__ uint32_t grp_bfly(uint32_t v) {
   else if constexpr (D == 8) return lane_dpp<0x140>(v);
   else return __shfl_xor(v, D, 64);
 }
-// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into 2 and 3)
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
-  return v;
-}
 
 // segmented scans over the G lanes of a read: members of the open segment to the left (pf) / right (sf) of a lane
 template <int G, int D>

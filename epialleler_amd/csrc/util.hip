@@ -9,14 +9,7 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                       // per thread
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;  // 4096 items per block
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int) { return wave_scan_u32(v); }
 
 // exclusive scan of one value per thread across a 256-thread block; returns exclusive prefix, *total = block sum
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *s_wave /* [5] */) {
