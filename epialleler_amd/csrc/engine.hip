@@ -168,7 +168,7 @@ static void parallel_memcpy(void *dst, const void *src, size_t len) {
   static const unsigned hw = std::thread::hardware_concurrency();
   const unsigned k = len < (4u << 20) ? 1u : (hw >= 8 ? 4u : hw >= 4 ? 2u : 1u);
   if (k == 1) { memcpy(dst, src, len); return; }
-  const size_t part = (len / k + 4095) & ~(size_t)4095;
+  const size_t part = ((len + k - 1) / k + 4095) & ~(size_t)4095;   // k * part >= len (len / k dropped up to k - 1 tail bytes)
   std::vector<std::thread> th;
   for (unsigned i = 1; i < k; i++) {
     const size_t o = part * i;

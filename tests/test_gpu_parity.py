@@ -172,6 +172,29 @@ def test_per_read_kernels_every_group_size(ea, mean_len):
         bam.close()
 
 
+def test_upload_keeps_the_last_bytes(ea):
+    """Regression: the threaded staging copy of epi_batch_upload split len bytes into 4 parts of len/4 rounded to 4 KiB and
+    dropped the last len % 4 bytes whenever len/4 was a multiple of 4096 (found by scratch/fuzz.py: one CX row short)."""
+    for nbytes in (4 * 1024 * 4096 + 3, 4 * 1200 * 4096 + 1, 2 * 64 * 1024 * 1024 + 4 * 512 * 4096 + 2):
+        n = nbytes // 1000
+        lens = np.full(n, 1000, np.int64)
+        lens[-1] += nbytes - int(lens.sum())
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        xm = np.full(nbytes, 0x1C, np.uint8)              # '.' everywhere
+        xm[-3:] = 0x17                                    # the last bases of the last read: 'Z'
+        t = dict(xm=xm, off=off, rname=np.ones(n, np.int32), strand=np.ones(n, np.int32),
+                 start=(1 + 10 * np.arange(n)).astype(np.int32))
+        bam = pb(ea, t)
+        try:
+            gb = ea.rcpp_get_xm_beta(bam, "Z", "z")
+            assert gb[-1] == 1.0 and gb[:-1].max() == 0.0, nbytes
+            got = ea.rcpp_cx_report(bam, None, "Z")
+            assert got["pos"].tolist()[-3:] == [int(t["start"][-1]) + int(lens[-1]) - 3 + i for i in range(3)], nbytes
+        finally:
+            bam.close()
+
+
 def test_tile_boundaries_and_large_positions(ea):
     rng = np.random.default_rng(5)
     # starts straddling multiples of the tile sizes (512/1024), near 2^31, and at position 0/1
