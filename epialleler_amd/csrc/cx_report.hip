@@ -682,15 +682,13 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   launch_cx_emit_slab(cx_tile_positions(), (int)b->shared_keys.size(), s, a, b->d_shared_owned.as<int32_t>(),
                       b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
-  {
-    uint32_t used = 0;   // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
-    EPI_TRY(read_scalars(b, s, cursor, 4, &used));
-    if ((size_t)a.ovf_base + used > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
-  }
   uint32_t *d_total = b->misc.as<uint32_t>() + 2;
   EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
-  uint32_t total = 0;
-  EPI_TRY(read_scalars(b, s, d_total, 4, &total));
+  uint32_t ut[2] = {0, 0};                                  // {overflow rows handed out, total rows}: one sync
+  EPI_TRY(read_scalars(b, s, cursor, 8, ut));
+  // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
+  if ((size_t)a.ovf_base + ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
+  const uint32_t total = ut[1];
   b->last_kind = 1;
   b->last_nrow = total;
   *nrow_out = total;
