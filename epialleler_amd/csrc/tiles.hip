@@ -140,10 +140,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
     for (int i = 0; i < TB_ITEMS; i++) s_tot[i][wave] = inc[i];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = bsum[blockIdx.x];                       // tiles created before this block (already scanned)
-    for (int i = 0; i < TB_ITEMS; i++)
-      for (int w = 0; w < TB_THREADS / 64; w++) { const uint32_t t = s_tot[i][w]; s_tot[i][w] = run; run += t; }
+  if (threadIdx.x < 64) {                                  // exclusive scan of the 32 (item, wave) totals by one wavefront
+    constexpr int NT = TB_ITEMS * (TB_THREADS / 64);
+    static_assert(NT <= 64, "one wavefront scans the wave totals");
+    uint32_t *flat = &s_tot[0][0];
+    const uint32_t t = lane < NT ? flat[lane] : 0u;
+    const uint32_t inc2 = wave_scan_u32(t);
+    if (lane < NT) flat[lane] = bsum[blockIdx.x] + inc2 - t;   // + the tiles created before this block (already scanned)
   }
   __syncthreads();
   const int64_t T = 1LL << sh;
