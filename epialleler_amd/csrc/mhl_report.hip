@@ -162,9 +162,8 @@ __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk_masks(const Ch
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int d = 2 * e + h;
-      const uint32_t c4 = r.ww[d] & 0x0F0F0F0Fu;
-      const uint32_t lo3 = c4 & 0x07070707u;
-      const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
+      const uint32_t lo3 = r.ww[d] & 0x07070707u;           // low three bits of the codes; bit 3 picks the LUT half
+      const uint32_t pick = ((r.ww[d] >> 1) & 0x04040404u) | 0x03020100u;
       uint32_t v = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
                                          __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
       if (edge) {
@@ -528,11 +527,8 @@ struct MhlArgs {
 #define MHL_CHECK(cond, code, v0, v1)
 #endif
 
-// nibble -> flags of the rarely taken per-byte path: stray nibbles 3 / 4 / 8, whose counter slot IS the numerator /
-// denominator / haplotype-size sum in the reference (:190)
-//   code:  0 1 2 3 4 5 6 7 | 8 9 10 11 | 12..15
-//   flag:  0 0 0 2 4 0 0 0 | 8 0  0  0 |  0
-constexpr uint32_t kFlagLo0 = 0x02000000u, kFlagLo1 = 0x00000004u, kFlagHi0 = 0x00000008u, kFlagHi1 = 0x00000000u;
+// (stray nibbles 3 / 4 / 8, whose counter slot IS the numerator / denominator / haplotype-size sum in the reference,
+// :190, are flagged by bits 6-7 of the packed counter LUT: tile_common.hpp)
 
 // ST = type of the LDS difference arrays: u64, or u32 when no tile (or heavy-tile chunk) of the batch can reach 2^31 in
 // any of the three sums -- decided on the host from the largest haplotype size pass 1 saw; u32 entries wrap like signed
@@ -606,21 +602,15 @@ __device__ __forceinline__ MhlSlice mhl_slice_of(const MhlArgs &a, const MhlRow 
 // position (+1 there, -1 after it, in the difference arrays).
 template <int OFF, bool FIRST, class ST>
 __device__ __forceinline__ void mhl_add_dword(uint32_t w, int k, const MhlSlice &m, const MhlLds<ST> &L) {
-  cx_add_dword<MHL_T, OFF, FIRST, true>(w, k == m.rs.nd - 1, m.rs);
-  const uint32_t c4 = w & 0x0F0F0F0Fu;
-  const uint32_t lo3 = c4 & 0x07070707u;
-  const uint32_t pick = 0x03020100u | ((c4 >> 1) & 0x04040404u);
-  uint32_t vm = k == m.rs.nd - 1 ? m.rs.mask_last : ~0u;
-  if (FIRST) vm &= m.rs.mask_first;
-  const uint32_t f4 = __builtin_amdgcn_perm(__builtin_amdgcn_perm(kFlagHi1, kFlagHi0, lo3),
-                                            __builtin_amdgcn_perm(kFlagLo1, kFlagLo0, lo3), pick) & vm;
+  // the packed counter LUT also flags the stray nibbles (bits 6-7 of its bytes: 1 = nibble 3, 2 = nibble 4, 3 = nibble 8)
+  const uint32_t f4 = cx_add_dword<MHL_T, OFF, FIRST, true>(w, k == m.rs.nd - 1, m.rs);
   if (f4 == 0u) return;                                  // common case: nothing but the counters
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const uint32_t fl = (f4 >> (8 * j)) & 0xFFu;
+    const uint32_t fl = (f4 >> (8 * j + 6)) & 3u;
     if (!fl) continue;
     const int p = m.pos0 + OFF + j;
-    ST *d = L.sums + ((fl & 2u) ? MHL_DN : (fl & 4u) ? MHL_DD : MHL_DH) + m.sidx * MHL_SLEN;
+    ST *d = L.sums + (fl == 1u ? MHL_DN : fl == 2u ? MHL_DD : MHL_DH) + m.sidx * MHL_SLEN;
     atomicAdd(d + mhl_pad(p), (ST)1);
     atomicAdd(d + mhl_pad(p + 1), (ST)0 - (ST)1);
   }

@@ -20,8 +20,9 @@ constexpr uint32_t kLutLo0 = 0x11121111u, kLutLo1 = 0x16141111u, kLutHi0 = 0x001
 // Packed variant (two u16 counters per LDS dword: pair 0 = ('.', other), 1 = (H, h), 2 = (X, x), 3 = (Z, z); the
 // even slot in the low half): byte = [increment of the high half: bits 4-5][pair: bits 2-3][increment of the low half: bits 0-1]
 //   code:     0    1    2    3    4    5    6    7 |   8    9   10   11 |  12   13   14   15
-//   byte:  0x10 0x10 0x05 0x10 0x10 0x10 0x09 0x0D | 0x10 0x20 0x14 0x00 | 0x01 0x10 0x18 0x1C
-constexpr uint32_t kPkLo0 = 0x10051010u, kPkLo1 = 0x0D091010u, kPkHi0 = 0x00142010u, kPkHi1 = 0x1C181001u;
+//   byte:  0x10 0x10 0x05 0x50 0x90 0x10 0x09 0x0D | 0xD0 0x20 0x14 0x00 | 0x01 0x10 0x18 0x1C
+// bits 6-7 (ignored by the counters) flag the stray nibbles the lMHL kernel needs: 1 = nibble 3, 2 = nibble 4, 3 = nibble 8
+constexpr uint32_t kPkLo0 = 0x50051010u, kPkLo1 = 0x0D091090u, kPkHi0 = 0x001420D0u, kPkHi1 = 0x1C181001u;
 constexpr int kCxGuard = 4;               // dwords of LDS padding around the counters (see cx_add_dword)
 
 struct RowCols {                          // the batch columns a tile kernel reads
@@ -109,7 +110,7 @@ __device__ __forceinline__ RowSlice cx_row_slice(const RowCols &a, const Tile &t
 // padding for that.  The byte order is rotated per lane (RowSlice::rot8) so that the 32 lanes of a half
 // wavefront always hit 32 different LDS banks.
 template <int T, int OFF, bool FIRST, bool PK = false>
-__device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSlice &m) {
+__device__ __forceinline__ uint32_t cx_add_dword(uint32_t w, bool last, const RowSlice &m) {   // returns the stray-nibble flags (packed LUT)
   const uint32_t lo3 = w & 0x07070707u;                  // low three bits of the four codes (unpack_ctx_idx)
   // 16-entry byte LUT = two v_perm lookups (codes 0-7 / 8-15) + a third v_perm that picks, per byte,
   // the second result when bit 3 of the code is set or the read is lower-cased (selector j + 4*bit3):
@@ -120,6 +121,7 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSli
   uint32_t vm = last ? m.mask_last : ~0u;
   if (FIRST) vm &= m.mask_first;
   s4 &= vm;
+  const uint32_t stray = s4 & 0xC0C0C0C0u;               // byte j = base j of the dword (before the rotation)
   s4 = __builtin_amdgcn_alignbit(s4, s4, m.rot8);        // rotate right by rot bytes: byte j <- byte (j+rot)&3
   if constexpr (PK) {
     // value added to the pair's dword = low increment | high increment << 16, put together by one v_perm per base
@@ -131,7 +133,7 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSli
       const uint32_t val = __builtin_amdgcn_perm(hi4, lo4, 0x0C000C00u | ((4u + j) << 16) | (uint32_t)j);
       atomicAdd(m.dst[j] + OFF + plane * T, val);
     }
-    return;
+    return stray;
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {                          // OFF = 4 * (this dword's index - the lane's first index)
@@ -141,6 +143,7 @@ __device__ __forceinline__ void cx_add_dword(uint32_t w, bool last, const RowSli
     const uint32_t inc = __builtin_amdgcn_ubfe(s4, 8 * j + 4, 2);
     atomicAdd(m.dst[j] + OFF + plane * T, inc);
   }
+  return 0u;
 }
 
 // LDS dwords of one tile's counters: u32 [strand][8][T], or packed u16 pairs [strand][4][T] (tile_common.hpp)
