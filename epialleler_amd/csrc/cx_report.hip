@@ -19,9 +19,11 @@
 // X, x, Z, z and "everything else that counts toward coverage" (U/u and any
 // other nibble; nibble 9 counts twice because the reference's coverage slot is
 // slot 9, :126-127).  Coverage is their sum, so ONE LDS atomic per base.
-// After a barrier the same workgroup applies the rule, compacts its rows in
-// position order (block scan), grabs a span of the row pool with one global
-// atomic and writes (key, meth, unmeth).  A scan over per-tile row counts
+// After a barrier the same workgroup applies the rule -- candidates first (cells
+// where a reported context has any count, listed per wavefront by ballot ranks),
+// then the rule on the listed cells -- and writes (key, meth, unmeth) in position
+// order into the tile's own slot of the row pool (no atomic; a tile with more rows
+// than a slot takes them from an overflow region).  A scan over per-tile row counts
 // then gives every tile its place in the final, ordered table (k_cx_gather).
 #include "common.hpp"
 #include "tile_common.hpp"

@@ -20,12 +20,14 @@
 //                their counted runs as records (M = 0).  Per read: h, or -1 when the
 //                read is dropped (h < hmin or out-of-context beta too high, :176-179).
 //  k_mhl_tiles   the CX tile kernel (packed LDS histogram, tile_common.hpp) plus three
-//                u64 DIFFERENCE arrays per strand in LDS: a read adds +h/-h and
-//                +S(h)/-S(h) at the ends of its in-tile slice and +S(M)/-S(M) at the
-//                ends of every record that reaches into the tile; the emit phase
-//                prefix-sums them.  S(n) = n(n+1)(n+2)/6 is computed arithmetically
-//                (no 64K-entry table).  512-position tiles, 41 KiB of LDS, three
-//                workgroups per CU.
+//                DIFFERENCE arrays per strand in LDS (u32 when no position can reach
+//                2^31, else u64): a read adds +h/-h and +S(h)/-S(h) at the ends of its
+//                in-tile slice and +S(M)/-S(M) at the ends of every record that reaches
+//                into the tile; the emit phase prefix-sums them (DPP wave scans).
+//                S(n) = n(n+1)(n+2)/6 is computed arithmetically (no 64K-entry table).
+//                512-position tiles, 30 (u32) or 44 (u64) KiB of LDS, three workgroups
+//                per CU; rows go to the tile's own slot of the row pool.
+// Lane exchanges inside groups of up to 16 lanes are DPP moves, not __shfl (ds_bpermute).
 #include "common.hpp"
 #include "tile_common.hpp"
 #include <stdio.h>
