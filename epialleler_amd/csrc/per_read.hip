@@ -2,7 +2,10 @@
 // and rcpp_get_xm_beta (src/rcpp_get_xm_beta.cpp:10-43).
 //
 // The reference builds a 16-bin histogram of the XM nibble per read and then
-// sums the bins named by each context string.  Here a group of G lanes owns one
+// sums the bins named by each context string.  Two kernels: k_per_read_wide
+// (default; further down: 8+ lanes per read, 4 reads per lane group, one LUT lookup
+// per dword for class strings without repeated letters) and the general k_per_read
+// below, where a group of G lanes owns one
 // read; every lane streams aligned 16-byte chunks of it (global_load_dwordx4),
 // maps four codes at a time to their per-class weights with two v_perm_b32
 // byte-LUT lookups (codes 0-7 / 8-15) and sums the four weight bytes with
