@@ -563,10 +563,16 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   uint32_t slot = slot_state > (uint32_t)(2 * T) ? (uint32_t)(2 * T) : slot_state;
   if (const char *env = getenv("EPIHIP_CX_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
-  const size_t ovf_base = (size_t)nt * slot;
-  {
+  size_t ovf_base = (size_t)nt * slot;
+  for (;;) {
     const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
-    if (b->pool_cap < ovf_base + ovf + headroom) EPI_TRY(ensure_pool(b, ovf_base + ovf + headroom));
+    if (b->pool_cap >= ovf_base + ovf + headroom) break;
+    const int rc = ensure_pool(b, ovf_base + ovf + headroom);
+    if (rc == EPI_OK) break;
+    b->pool_cap = 0;                                       // (a failed growth has released the old buffers)
+    if (!slot) return rc;
+    slot = 0;                                              // the slots do not fit in device memory: every tile through the
+    ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
   const int grp = pick_cx_group(st.max_len, T);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total

@@ -1168,10 +1168,16 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   uint32_t slot = b->mhl_slot > 2u * MHL_T ? 2u * MHL_T : b->mhl_slot;
   if (const char *env = getenv("EPIHIP_MHL_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * MHL_T) slot = (uint32_t)v; }
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
-  const size_t ovf_base = (size_t)nt * slot;
-  {
+  size_t ovf_base = (size_t)nt * slot;
+  for (;;) {
     const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
-    if (mhl_pool_rows(b) < ovf_base + ovf + headroom) EPI_TRY(ensure_mhl_pool(b, ovf_base + ovf + headroom));
+    if (mhl_pool_rows(b) >= ovf_base + ovf + headroom) break;
+    const int rc = ensure_mhl_pool(b, ovf_base + ovf + headroom);
+    if (rc == EPI_OK) break;
+    b->pool_cap = 0; b->pool_cap2 = 0;                     // (a failed growth has released the old buffers)
+    if (!slot) return rc;
+    slot = 0;                                              // the slots do not fit in device memory: every tile through the cursor
+    ovf_base = 0;
   }
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;
