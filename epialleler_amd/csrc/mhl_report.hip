@@ -36,7 +36,10 @@
 
 namespace epi {
 
-constexpr int MHL_WG = 512;
+constexpr int MHL_WG = 512;                       // threads per workgroup of the heavy-tile and slab kernels
+constexpr int MHL_WG_SHORT = 256;                 // k_mhl_tiles for reads of one k_mhl_rows block: five workgroups per CU,
+                                                  // 10.8 against 11.6 ms on config 4 (long reads, whose record walk is
+                                                  // latency-bound, keep 512: 9.4 against 12.4 ms on 10 kb reads)
 constexpr int MHL_T = kMhlTile;
 // One difference array: entry of tile position p (0..T, T = "after the tile") sits at p + p/8 -- the padding makes the
 // prefix-sum phase, where a lane walks 8 consecutive entries, free of LDS bank conflicts (stride 9 x 8 bytes per lane).
@@ -735,14 +738,15 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   constexpr int PER = T / 64;                             // positions per lane in the prefix-sum phase
-  static_assert(WG == T && NW >= 6, "one position per thread in the emit phase, one wavefront per difference array");
+  constexpr int PPT = T / WG;                             // consecutive positions per thread in the emit phase
+  constexpr int NS = 2 * PPT;                             // (pos, strand) cells per thread, in key order
+  static_assert(PPT == 1 || PPT == 2, "emit phase layout");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = threadIdx.x;
-  // in-place inclusive prefix sums of the six difference arrays: wavefront i takes array i (serial over a lane's
-  // PER consecutive positions, one 64-lane scan of the lane totals)
-  if (wave < 6) {
+  // in-place inclusive prefix sums of the six difference arrays: a wavefront takes arrays wave, wave + NW, ... (serial
+  // over a lane's PER consecutive positions, one 64-lane scan of the lane totals)
+  for (int ai = wave; ai < 6; ai += NW) {
     static_assert(PER == 8, "the padding of the difference arrays assumes 8 entries per lane");
-    ST *arr = L.sums + wave * MHL_SLEN + lane * (PER + 1);
+    ST *arr = L.sums + ai * MHL_SLEN + lane * (PER + 1);
     ST x[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) x[j] = arr[j];
@@ -754,12 +758,13 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     for (int j = 0; j < PER; j++) arr[j] = x[j] + ex;
   }
   __syncthreads();
-  uint32_t key[2], cov[2];
-  unsigned long long hs[2], nu[2], de[2];
-  bool ok[2];
+  uint32_t key[NS], cov[NS];
+  unsigned long long hs[NS], nu[NS], de[NS];
+  bool ok[NS];
   int nr = 0;
 #pragma unroll
-  for (int s = 0; s < 2; s++) {
+  for (int i = 0; i < NS; i++) {
+    const int p = (int)threadIdx.x * PPT + (i >> 1), s = i & 1;
     uint32_t c[8];
     if constexpr (PK) {
 #pragma unroll
@@ -783,19 +788,23 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
     else if (nX > half) { k = 6; cc = nX; }
     else if (nZ > half) { k = 7; cc = nZ; }
     if (k && !((a.ctx_mask >> k) & 1u)) k = 0;                               // :86
-    ok[s] = k != 0;
-    key[s] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
-    cov[s] = cc;                                                             // :90
-    hs[s] = L.sums[MHL_DH + s * MHL_SLEN + mhl_pad(p)];                      // :92 numerator
-    nu[s] = L.sums[MHL_DN + s * MHL_SLEN + mhl_pad(p)];                      // :93 numerator
-    de[s] = L.sums[MHL_DD + s * MHL_SLEN + mhl_pad(p)];                      // :93 denominator
+    ok[i] = k != 0;
+    key[i] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | (uint32_t)k;
+    cov[i] = cc;                                                             // :90
+    hs[i] = L.sums[MHL_DH + s * MHL_SLEN + mhl_pad(p)];                      // :92 numerator
+    nu[i] = L.sums[MHL_DN + s * MHL_SLEN + mhl_pad(p)];                      // :93 numerator
+    de[i] = L.sums[MHL_DD + s * MHL_SLEN + mhl_pad(p)];                      // :93 denominator
     nr += k != 0;
   }
-  // rows of the lower lanes from two ballots (a lane has 0..2 rows: one per strand), no shuffle scan
-  const unsigned long long b0 = __ballot(ok[0]), b1 = __ballot(ok[1]);
-  const uint32_t inc = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-                       __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) + (uint32_t)nr;
-  if (lane == 0) s_scan[wave] = (uint32_t)(__popcll(b0) + __popcll(b1));
+  // rows of the lower lanes from one ballot per cell (a lane has 0..NS rows), no shuffle scan
+  uint32_t inc = (uint32_t)nr, wtot = 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    const unsigned long long bi = __ballot(ok[i]);
+    inc += __builtin_amdgcn_mbcnt_hi((uint32_t)(bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bi, 0u));
+    wtot += (uint32_t)__popcll(bi);
+  }
+  if (lane == 0) s_scan[wave] = wtot;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
@@ -821,13 +830,13 @@ __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLd
   if (total != 0xFFFFFFFFu) {
     uint32_t w = base + inc - (uint32_t)nr + s_scan[wave];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      if (ok[s]) {
-        a.pool_key[w] = key[s];
-        a.pool_cov[w] = cov[s];
-        a.pool_hs[w] = hs[s];
-        a.pool_nu[w] = nu[s];
-        a.pool_de[w] = de[s];
+    for (int i = 0; i < NS; i++) {
+      if (ok[i]) {
+        a.pool_key[w] = key[i];
+        a.pool_cov[w] = cov[i];
+        a.pool_hs[w] = hs[i];
+        a.pool_nu[w] = nu[i];
+        a.pool_de[w] = de[i];
         w++;
       }
     }
@@ -846,7 +855,10 @@ __device__ __forceinline__ MhlLds<ST> mhl_lds(uint32_t *cnt, ST *sums) {
 
 // three workgroups per CU (6 waves per SIMD, 80 VGPRs) for both sum types: with u32 sums (30 KiB of LDS) a fourth would
 // fit, but at 64 VGPRs the kernel spills 33 of them and runs 26 ms instead of 13.7 on config 4 (u64: 17.5)
-template <class ST> constexpr int mhl_waves_per_simd() { return sizeof(ST) == 4 ? EPI_MHL_WPS : 6; }
+template <int WG, class ST> constexpr int mhl_waves_per_simd() {
+  if (WG == 256) return sizeof(ST) == 4 ? 5 : 3;          // as many 256-thread workgroups as LDS holds: 5 x 30 KiB / 3 x 44 KiB
+  return sizeof(ST) == 4 ? EPI_MHL_WPS : 6;
+}
 
 // adds a tile's LDS difference arrays to its u64 slab in HBM
 template <int WG, class ST>
@@ -855,7 +867,7 @@ __device__ __forceinline__ void mhl_dump_sums(const ST *sums, unsigned long long
 }
 
 template <int G, int WG, class ST>
-__global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_tiles(MhlArgs a, int ntiles) {
+__global__ __launch_bounds__(WG, (mhl_waves_per_simd<WG, ST>())) void k_mhl_tiles(MhlArgs a, int ntiles) {
   constexpr int T = MHL_T;
   constexpr int NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
@@ -898,7 +910,7 @@ __global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_tiles(Mh
 
 // One chunk of the candidate rows of one heavy tile -> added into that tile's slab in HBM.
 template <int G, int WG, class ST>
-__global__ __launch_bounds__(WG, (mhl_waves_per_simd<ST>())) void k_mhl_heavy(MhlArgs a) {
+__global__ __launch_bounds__(WG, (mhl_waves_per_simd<WG, ST>())) void k_mhl_heavy(MhlArgs a) {
   constexpr int T = MHL_T;
   __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MHL_LDS_CNT];
   __shared__ __attribute__((aligned(16))) ST sums[MHL_NSUM];
@@ -1000,15 +1012,23 @@ static int ensure_mhl_pool(epi_batch *b, size_t rows) {
   return EPI_OK;
 }
 
-template <class ST>
-static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
+template <int WG, class ST>
+static void launch_mhl_tiles_wg(int g, int nt, hipStream_t s, const MhlArgs &a) {
   const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_mhl_tiles<8, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_mhl_tiles<16, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_mhl_tiles<32, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_mhl_tiles<64, MHL_WG, ST>), dim3(grid), dim3(MHL_WG), 0, s, a, nt); break;
+    case 8: hipLaunchKernelGGL((k_mhl_tiles<8, WG, ST>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_mhl_tiles<16, WG, ST>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_mhl_tiles<32, WG, ST>), dim3(grid), dim3(WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_mhl_tiles<64, WG, ST>), dim3(grid), dim3(WG), 0, s, a, nt); break;
   }
+}
+
+template <class ST>
+static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
+  static int wg_env = -1;                                  // EPIHIP_MHL_WG=256/512 forces one (tests, A/B runs)
+  if (wg_env < 0) { wg_env = 0; if (const char *env = getenv("EPIHIP_MHL_WG")) { const int v = atoi(env); if (v == 256 || v == 512) wg_env = v; } }
+  const int wg = wg_env ? wg_env : (a.multi ? MHL_WG : MHL_WG_SHORT);
+  if (wg == 256) launch_mhl_tiles_wg<256, ST>(g, nt, s, a); else launch_mhl_tiles_wg<512, ST>(g, nt, s, a);
 }
 
 template <class ST>

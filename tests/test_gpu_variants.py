@@ -25,6 +25,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
     {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL: nearly every tile outgrows its pool slot
     {"EPIHIP_MHL_SLOT": "0"},
+    {"EPIHIP_MHL_WG": "512", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL tile kernel with 512-thread workgroups for short reads too
+    {"EPIHIP_MHL_WG": "256", "EPIHIP_MHL_MULTI": "1"},                   # ... and 256 with the per-block records of long reads
     {"EPIHIP_MHL_MULTI": "1"},                                           # lMHL pass 1: wavefront-per-read kernel for every read
     {"EPIHIP_MHL_MULTI": "1", "EPIHIP_MHL_TILE_GROUP": "64", "EPIHIP_HEAVY_ROWS": "500"},
     {"EPIHIP_MHL_SUMS": "64", "EPIHIP_HEAVY_ROWS": "500"},              # lMHL pass 2 with u64 LDS sums where u32 would do
