@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mreads/s of generateCytosineReport() on synthetic PE150
 templates resident in HBM (BASELINE.json metric; config 2 at N=1, weak-scaled by
-row-range shards at N>1).  One process per GPU; N>1 is launched by
-torch.distributed.run and uses RCCL (backend "nccl") for the one shared-tile
-all-reduce and the row gather.
+row-range shards at N>1).  One process per GPU over RCCL (backend "nccl") for the
+one shared-tile all-reduce and the row gather.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run children)
 
-A "step" is one full generateCytosineReport(bam) on the resident batch: the
-thresholding kernel, the tile index, the LDS-histogram tile kernel with the
-majority rule, and the ordered gather into the six output columns (which stay in
-HBM, as the input does).  A "read" is one template row (a merged read pair).
+A "step" is one full generateCytosineReport(bam) on the resident batch: thresholding,
+the tile index, the LDS-histogram tile kernel with the majority rule, and the ordered
+gather into the six output columns (which stay in HBM, as the input does).  A "read"
+is one template row (a merged read pair).
+
+Besides the contract line's `value` (inputs resident in HBM) the N=1 line carries
+  streamed   the same report with the batch starting in pinned host memory (upload + report), SURVEY 8d
+  d2h        the report table copied to pinned host memory
+  cfg2u      the SURVEY-8d-conformant variant of the workload (uniform-random starts sorted on device,
+             ragged template lengths, a 50-byte 0xFB gap between the mates of every fourth template)
+  strong_cfg3  BASELINE config 3 (100 M templates in total, split over the N GPUs)
+and every N>1 run first checks, on a reduced-size stream, that the sharded table equals the single-GPU table.
 """
 import argparse
 import json
@@ -26,6 +34,9 @@ WORKLOADS = {
     "cfg2": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG",
                  desc="simulateBam-like 10M PE150 templates (L=300, depth 30, 4 chr), generateCytosineReport defaults "
                       "(threshold.reads=TRUE, CG)"),
+    "cfg2u": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", uniform=True,
+                  desc="as cfg2 with uniform-random starts (sorted on device), template lengths 240-360 and a 50-byte "
+                       "0xFB gap in every fourth template"),
     "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX",
                    desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE, report.context='CX')"),
     "cfg3": dict(rows=100_000_000, strong=True, read_len=300, kind="cx", threshold=True, report_context="CG",
@@ -36,7 +47,7 @@ WORKLOADS = {
 }
 
 
-def main():
+def _parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -44,177 +55,386 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--read-len", type=int, default=0, help="override the template length of the workload (experiments)")
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="rows timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rows timed on the CPU oracle (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--gather", action="store_true", help="N>1: also send every rank's rows to rank 0 inside the timed step")
-    ap.add_argument("--check", action="store_true", help="rank 0 checks the gathered table against a single-GPU run of the whole stream")
-    args = ap.parse_args()
+    ap.add_argument("--check", action="store_true", help="N>1: rank 0 checks the FULL-size gathered table against a single-GPU "
+                                                         "run of the whole stream (a reduced-size check always runs)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N>1: skip the reduced-size sharded == single-GPU check")
+    ap.add_argument("--selfcheck-rows", type=int, default=600_000, help="N>1: total rows of the reduced-size check")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract fields (no streamed / d2h / cfg2u / strong_cfg3)")
+    ap.add_argument("--strong-steps", type=int, default=3)
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.share_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    import epialleler_amd as ea
-    from epialleler_amd import _lib, distributed as D, synth
-    lib = _lib.load()
 
+def _launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process becomes a pure
+    launcher.  It has not touched HIP (torch is not even imported here) and never execs: the N ranks are fresh child
+    processes started by torch.distributed.run; their output is relayed and the exit code is the children's."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+class Ctx:
+    """What every measurement below needs: the rank layout, torch, the library."""
+
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.np, self.torch, self.dist, self.args = np, torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(args.backend)
+        import epialleler_amd as ea
+        from epialleler_amd import _lib, distributed as D, synth
+        self.ea, self.D, self.synth, self.lib = ea, D, synth, _lib.load()
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world == 1:
+            return dt
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v):
+        if self.world == 1:
+            return int(v)
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+
+def make_batch(cx, wl, rows, L, n_total):
+    if wl.get("uniform"):
+        return cx.synth.generate_device_uniform(n_total=n_total, mean_len=L, row_first=cx.rank * rows, n=rows, device=cx.local)
+    return cx.synth.generate_device(n_total=n_total, read_len=L, row_first=cx.rank * rows, n=rows, device=cx.local)
+
+
+def make_step(cx, wl, bam, eng, gather):
+    ea, D = cx.ea, cx.D
+    if wl["kind"] == "mhl":
+        if cx.world == 1:
+            return lambda: ea.generateMhlReport(bam, as_device=True)
+        return lambda: D.sharded_mhl(eng, gather=gather, levels=bam.levels)
+    if cx.world == 1:
+        return lambda: ea.generateCytosineReport(bam, threshold_reads=wl["threshold"], report_context=wl["report_context"],
+                                                 as_device=True)
+    return lambda: D.sharded_cytosine_report(eng, threshold_reads=wl["threshold"], report_context=wl["report_context"],
+                                             gather=gather, levels=bam.levels)
+
+
+def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False):
+    """W untimed + exactly K timed steps of `wl` on `rows` rows per rank, barrier + synchronize on both sides,
+    max over ranks.  Returns a dict (and the batch / last report when keep=True)."""
+    import ctypes as C
+    n_total = rows * cx.world
+    bam = make_batch(cx, wl, rows, L, n_total)
+    cx.torch.cuda.synchronize()
+    eng = cx.D.HipShardEngine(bam) if cx.world > 1 else None
+    step = make_step(cx, wl, bam, eng, gather)
+    # setup, not steps: the first calls size the engine's row pool / record space for this workload and the caching
+    # allocator's blocks for the two output tables that are alive at a time (rep = step() frees the previous one late)
+    rep = step()
+    rep = step()
+    for _ in range(warmup):
+        rep = step()
+    cx.barrier()
+    cx.lib.epi_prof_reset()
+    cx.lib.epi_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = step()
+    cx.barrier()
+    dt = time.perf_counter() - t0
+    cx.lib.epi_prof_enable(0)
+    dt = cx.max_over_ranks(dt)
+    kernels = {}
+    for nm in (b"threshold", b"cx_tiles", b"cx_heavy", b"mhl_rows", b"mhl_tiles", b"tile_index", b"gather"):
+        m2, c2 = C.c_double(0), C.c_int64(0)
+        cx.lib.epi_prof_get(nm, C.byref(m2), C.byref(c2))
+        if c2.value:
+            kernels[nm.decode()] = round(m2.value / c2.value, 4)
+    nrow_local = rep.nrow if rep is not None else 0
+    out = dict(dt=dt, ms_per_step=dt / steps * 1e3, n_total=n_total, rows=rows, L=L, kernels=kernels,
+               nrow_local=nrow_local, nbytes_local=bam.nbytes,
+               exchange_bytes=getattr(eng, "last_exchange_bytes", 0) if eng is not None else 0)
+    if keep:
+        out["bam"], out["rep"], out["eng"] = bam, rep, eng
+    else:
+        del rep, step, eng
+        bam.close()
+    return out
+
+
+def selfcheck(cx, n_total):
+    """N>1: the sharded table of a reduced-size stream, gathered on rank 0, must equal the single-GPU table of the
+    same stream (CX with thresholding, and lMHL).  Every rank raises on a mismatch."""
+    torch, ea, D = cx.torch, cx.ea, cx.D
+    rows = (n_total + cx.world - 1) // cx.world
+    n_total = rows * cx.world
+    bam = cx.synth.generate_device(n_total=n_total, read_len=300, row_first=cx.rank * rows, n=rows, device=cx.local, seed=5)
+    eng = D.HipShardEngine(bam)
+    got_cx = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True, levels=bam.levels)
+    got_mhl = D.sharded_mhl(eng, gather=True, levels=bam.levels)
+    ok = 1
+    nrow = 0
+    if cx.rank == 0:
+        whole = cx.synth.generate_device(n_total=n_total, read_len=300, device=cx.local, seed=5)
+        ref_cx = ea.generateCytosineReport(whole, threshold_reads=True, report_context="CG", as_device=True)
+        ref_mhl = ea.generateMhlReport(whole, as_device=True)
+        ok = int(all(bool(torch.equal(ref_cx[k], got_cx[k])) for k in ref_cx) and
+                 all(bool(torch.equal(ref_mhl[k].view(torch.int64) if ref_mhl[k].dtype == torch.float64 else ref_mhl[k],
+                                      got_mhl[k].view(torch.int64) if got_mhl[k].dtype == torch.float64 else got_mhl[k]))
+                     for k in ref_mhl))
+        nrow = ref_cx.nrow
+        whole.close()
+    t = torch.tensor([ok], dtype=torch.int64, device=cx.dev)
+    cx.dist.broadcast(t, src=0)
+    bam.close()
+    if int(t.item()) != 1:
+        raise SystemExit("selfcheck FAILED: sharded table differs from the single-GPU table (%d rows over %d ranks)" % (n_total, cx.world))
+    return {"rows_total": n_total, "cx_rows": nrow, "ok": True, "what": "sharded CX (thresholded) and lMHL tables, gathered "
+            "on rank 0 over %s, bit-equal to the single-GPU tables of the same stream" % cx.args.backend}
+
+
+def streamed_and_d2h(cx, wl, res):
+    """N=1: the same report when the batch starts in pinned host memory (what preprocessBam hands over): upload
+    (hipMemcpyAsync straight from the pinned columns) + report; and the finished table copied to pinned host memory."""
+    torch, ea = cx.torch, cx.ea
+    bam = res["bam"]
+    host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v) for k, v in bam.dev.items()}
+    torch.cuda.synchronize()
+    step_kw = dict(threshold_reads=wl["threshold"], report_context=wl["report_context"], as_device=True)
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hb = ea.ProcessedBam.from_pinned(host["xm"], bam.nbytes, host["off"], host["rname"], host["strand"], host["start"],
+                                         bam.levels, device=cx.local)
+        rep = ea.generateCytosineReport(hb, **step_kw)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        hb.close()
+    t_stream = min(times[1:])
+    rep = res["rep"]
+    pinned = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in rep.items()}
+    d2h = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k, v in rep.items():
+            pinned[k].copy_(v, non_blocking=True)
+        torch.cuda.synchronize()
+        d2h.append(time.perf_counter() - t0)
+    table_bytes = sum(v.numel() * v.element_size() for v in rep.values())
+    in_bytes = sum(v.numel() * v.element_size() for v in host.values())
+    return ({"value": round(res["n_total"] / t_stream / 1e6, 2), "unit": "Mreads/s", "ms": round(t_stream * 1e3, 3),
+             "host_bytes": int(in_bytes), "GBps_pcie": round(in_bytes / t_stream / 1e9, 2),
+             "what": "pinned host SoA -> hipMemcpyAsync -> HBM -> one report (upload + report, best of 2 after a warm-up)"},
+            {"ms": round(min(d2h) * 1e3, 3), "bytes": int(table_bytes), "GBps": round(table_bytes / min(d2h) / 1e9, 2),
+             "what": "the report table (6 int32 columns) copied to pinned host memory"})
+
+
+def main():
+    args = _parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _launch_ranks(args)
+    cx = Ctx(args)
+    np, torch = cx.np, cx.torch
+    world, rank = cx.world, cx.rank
     wl = WORKLOADS[args.workload]
     rows = args.rows or wl["rows"]
     if wl.get("strong"):
         rows = (rows + world - 1) // world                      # fixed total: BASELINE config 3 is a strong-scaling case
     L = args.read_len or wl["read_len"]
-    n_total = rows * world
-    bam = synth.generate_device(n_total=n_total, read_len=L, row_first=rank * rows, n=rows, device=local)
-    torch.cuda.synchronize()
 
-    eng = D.HipShardEngine(bam) if world > 1 else None
+    check = None
+    if world > 1 and not args.no_selfcheck:
+        check = selfcheck(cx, args.selfcheck_rows)
+    ranks_seen = cx.sum_over_ranks(1)
 
-    def step():
-        if wl["kind"] == "mhl":
-            return ea.generateMhlReport(bam, as_device=True)
-        if world == 1:
-            return ea.generateCytosineReport(bam, threshold_reads=wl["threshold"], report_context=wl["report_context"],
-                                             as_device=True)
-        return D.sharded_cytosine_report(eng, threshold_reads=wl["threshold"], report_context=wl["report_context"],
-                                         gather=args.gather or args.check, levels=bam.levels)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # setup, not steps: the first calls size the engine's row pool / record space for this workload and the caching
-    # allocator's blocks for the two output tables that are alive at a time (rep = step() frees the previous one late)
-    rep = step()
-    rep = step()
-    for _ in range(args.warmup):
-        rep = step()
-    barrier()
-    lib.epi_prof_reset()
-    lib.epi_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rep = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    lib.epi_prof_enable(0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # dominant kernel, timed with HIP events on the stream it is launched on (library hook)
-    import ctypes as C
-    kname = b"mhl_tiles" if wl["kind"] == "mhl" else b"cx_tiles"
-    ms, cnt = C.c_double(0), C.c_int64(0)
-    lib.epi_prof_get(kname, C.byref(ms), C.byref(cnt))
-    kernels = {}
-    for nm in (b"threshold", b"cx_tiles", b"mhl_rows", b"mhl_tiles"):
-        m2, c2 = C.c_double(0), C.c_int64(0)
-        lib.epi_prof_get(nm, C.byref(m2), C.byref(c2))
-        if c2.value:
-            kernels[nm.decode()] = round(m2.value / c2.value, 4)
+    gathered = world > 1 and (args.gather or args.check)
+    res = timed_run(cx, wl, rows, L, args.steps, args.warmup, gather=gathered, keep=True)
+    bam, rep = res["bam"], res["rep"]
+    n_total = res["n_total"]
 
     if args.check and world > 1 and rank == 0 and wl["kind"] == "cx":
-        whole = synth.generate_device(n_total=n_total, read_len=L, device=local)
-        ref = ea.generateCytosineReport(whole, threshold_reads=wl["threshold"], report_context=wl["report_context"], as_device=True)
+        whole = cx.synth.generate_device(n_total=n_total, read_len=L, device=cx.local)
+        ref = cx.ea.generateCytosineReport(whole, threshold_reads=wl["threshold"], report_context=wl["report_context"], as_device=True)
         ok = all(bool(torch.equal(ref[k], rep[k])) for k in ref)
         print("CHECK sharded == single-GPU table: %s (%d rows)" % (ok, ref.nrow), flush=True)
         whole.close()
         if not ok:
             raise SystemExit("sharded result differs from the single-GPU result")
-    gathered = world > 1 and (args.gather or args.check)
-    nrow_local = rep.nrow if rep is not None else 0
-    nrow_out = nrow_local
-    if world > 1 and not gathered:
-        tot = torch.tensor([nrow_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
-        nrow_out = int(tot.item())
+    nrow_local = res["nrow_local"]
+    nrow_out = nrow_local if gathered or world == 1 else cx.sum_over_ranks(nrow_local)
+    if gathered and world > 1:
+        nrow_out = cx.sum_over_ranks(nrow_local if rank == 0 else 0)
+
+    out = None
     if rank == 0:
+        kname = "mhl_tiles" if wl["kind"] == "mhl" else "cx_tiles"
         rows_this_rank = nrow_local if not gathered else nrow_out // world   # rows rank 0's kernel emitted
         row_bytes = 36 if wl["kind"] == "mhl" else 24
         # SURVEY 8(d): L (xm) + 8 (off) + 12 (rname,strand,start) + 4 (pass) per read, + 24/36 B per output row
-        alg_bytes = rows * (L + 8 + 12 + 4) + row_bytes * rows_this_rank
-        kms = ms.value / max(cnt.value, 1)
+        alg_bytes = res["nbytes_local"] + rows * (8 + 12 + 4) + row_bytes * rows_this_rank
+        kms = res["kernels"].get(kname, 0.0)
         achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        traffic = None
+        traffic, tsrc = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(kname.decode())
+                tj = json.load(open(tfile)).get(args.workload, {})
+                if tj.get("rows_per_gpu", rows) == rows and not args.read_len:
+                    traffic = tj.get(kname)
+                    tsrc = "static: %s, rocprofv3 --pmc passes of this workload at this size (%s)" % (
+                        os.path.relpath(tfile, ROOT), tj.get("source", "profiles/"))
             except Exception:
                 traffic = None
         out = {
             "metric": "Mreads/s generateCytosineReport (150 bp PE)" if wl["kind"] == "cx" and L == 300 else
                       "Mreads/s %s" % ("generateMhlReport" if wl["kind"] == "mhl" else "generateCytosineReport (long reads)"),
-            "value": round(n_total * args.steps / dt / 1e6, 3),
+            "value": round(n_total * args.steps / res["dt"] / 1e6, 3),
             "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(res["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "strong" if wl.get("strong") else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
                        "inputs": "resident in HBM", "sharding": ("row ranges; shared tiles all-reduced (RCCL); output rows %s"
                                     % ("gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": kname.decode(), "achieved": round(achieved, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kms, 4),
-                         "kernel_ms_all": kernels},
+                         "kernel_ms_all": res["kernels"],
+                         "step_frac": round(alg_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / 8000.0, 5)},
+            "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+            "all_reduce_bytes_per_step": int(res["exchange_bytes"]), "selfcheck": check,
         }
-        if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(bam, wl, min(args.cpu_sample, rows), np)
-        else:
-            out["cpu_baseline"] = None                   # --cpu-sample 0 / N > 1: not timed in this run
+    extras = not args.no_extras and not args.rows and not args.read_len
+    if world == 1 and extras and wl["kind"] == "cx" and L <= 1000 and out is not None:
+        out["streamed"], out["d2h"] = streamed_and_d2h(cx, wl, res)
+    if world == 1 and args.cpu_sample > 0 and out is not None:
+        out["cpu_baseline"] = cpu_baseline(bam, wl, min(args.cpu_sample, rows), np)
+    elif out is not None:
+        out["cpu_baseline"] = None                   # --cpu-sample 0 / N > 1: not timed in this run
+    del rep
+    res.pop("rep", None); res.pop("eng", None)
+    bam.close()
+    del bam
+    res.pop("bam", None)
+    torch.cuda.empty_cache()
+
+    if extras and args.workload == "cfg2":
+        if world == 1:
+            u = timed_run(cx, WORKLOADS["cfg2u"], rows, L, max(3, args.steps // 2), 1)
+            if out is not None:
+                out["cfg2u"] = {"value": round(u["n_total"] * max(3, args.steps // 2) / u["dt"] / 1e6, 3), "unit": "Mreads/s",
+                                "ms_per_step": round(u["ms_per_step"], 4), "vs_cfg2": round(u["ms_per_step"] / res["ms_per_step"], 3),
+                                "kernel_ms_all": u["kernels"], "what": WORKLOADS["cfg2u"]["desc"]}
+        w3 = WORKLOADS["cfg3"]
+        r3 = (w3["rows"] + world - 1) // world
+        s3 = timed_run(cx, w3, r3, w3["read_len"], args.strong_steps, 1)
+        if out is not None:
+            out["strong_cfg3"] = {"value": round(s3["n_total"] * args.strong_steps / s3["dt"] / 1e6, 3), "unit": "Mreads/s",
+                                  "rows_total": s3["n_total"], "rows_per_gpu": r3, "n_gpus": world, "steps": args.strong_steps,
+                                  "ms_per_step": round(s3["ms_per_step"], 4), "scaling": "strong",
+                                  "all_reduce_bytes_per_step": int(s3["exchange_bytes"]), "kernel_ms_all": s3["kernels"],
+                                  "what": w3["desc"]}
+    if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        cx.dist.barrier()
+        cx.dist.destroy_process_group()
+
+
+def _oracle_report(args):
+    """One oracle pass (module-level so that a process pool can run it)."""
+    xm, off, rname, strand, start, kind, threshold, letters = args
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    if kind == "mhl":
+        orc.mhl_report(xm, off, rname, strand, start, "Zz", 0, 0, 0.1)
+    else:
+        p = orc.threshold_reads(xm, off, "Z", "z", "XH", "xh", 2, 0.5, 0.1) if threshold else None
+        orc.cx_report(xm, off, rname, strand, start, p, letters)
+    return time.perf_counter() - t0
 
 
 def cpu_baseline(bam, wl, sample, np):
     """The CPU restatement of the reference algorithm (oracle/epi_oracle.c, kind "port": same per-base ordered-map
     emplace and flush rule as src/rcpp_cx_report.cpp), one thread (the reference is single-threaded), on the first
-    `sample` rows of the same synthetic stream."""
-    from oracle import oracle as orc
+    `sample` rows of the same synthetic stream; plus, labelled as not a reference feature, P independent oracle
+    processes on disjoint row ranges of the stream ("all host cores")."""
     d = bam.dev
-    off = d["off"][:sample + 1].cpu().numpy()
-    xm = d["xm"][:int(off[-1])].cpu().numpy()
-    rname, strand, start = (d[k][:sample].cpu().numpy() for k in ("rname", "strand", "start"))
-    c = {"CG": ("Z", "z", "XH", "xh"), "CX": ("ZXH", "zxh", "", "")}
-    t0 = time.perf_counter()
-    if wl["kind"] == "mhl":
-        orc.mhl_report(xm, off, rname, strand, start, "Zz", 0, 0, 0.1)
-    else:
-        p = None
-        if wl["threshold"]:
-            p = orc.threshold_reads(xm, off, *c["CG"], 2, 0.5, 0.1)
-        letters = c[wl["report_context"]][0]
-        orc.cx_report(xm, off, rname, strand, start, p, letters)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
-            "sample": "first %d rows of the same synthetic stream, %.1f s of CPU work" % (sample, dt)}
+    letters = {"CG": "Z", "CX": "ZXH"}.get(wl.get("report_context", "CG"), "Z")
+
+    def rows_of(lo, hi):
+        off = d["off"][lo:hi + 1].cpu().numpy()
+        xm = d["xm"][int(off[0]):int(off[-1])].cpu().numpy()
+        return (xm, off - off[0], d["rname"][lo:hi].cpu().numpy(), d["strand"][lo:hi].cpu().numpy(),
+                d["start"][lo:hi].cpu().numpy(), wl["kind"], wl.get("threshold", False), letters)
+
+    dt = _oracle_report(rows_of(0, sample))
+    out = {"value": round(sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+           "sample": "first %d rows of the same synthetic stream, %.1f s of CPU work" % (sample, dt)}
+    try:
+        from concurrent.futures import ThreadPoolExecutor      # the oracle is a C library without global state and
+        P = max(1, min(os.cpu_count() or 1, 16))               # ctypes drops the GIL: threads = independent oracle runs
+        per = max(1, min(sample // 2, bam.n // P))
+        parts = [rows_of(i * per, (i + 1) * per) for i in range(P)]
+        cpu_model = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(P) as pool:
+            list(pool.map(_oracle_report, parts))
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(P * per / wall / 1e6, 4), "unit": "Mreads/s", "cores": P, "cpu": cpu_model,
+                            "sample": "%d concurrent oracle runs x %d rows (disjoint row ranges of the stream), %.1f s wall" % (P, per, wall),
+                            "note": "not a reference feature: epialleleR runs single-threaded (vignettes/epialleleR.Rmd:160-165)"}
+    except Exception as e:                                   # the single-thread figure is the baseline; this one is extra
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 if __name__ == "__main__":

@@ -110,6 +110,7 @@ _SIGS = {
     "epi_batch_mhl_set_shared": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     "epi_batch_mhl_finish_shared": (C.c_int, [_VP, _VP, C.POINTER(_I64)]),
     "epi_synth_generate_dev": (C.c_int, [C.POINTER(SynthParams), _VP, _VP, _VP, _VP, _VP, _VP]),
+    "epi_synth_fill_dev": (C.c_int, [C.c_uint64, _I64, _I64, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP, _VP]),
     "epi_prof_enable": (None, [C.c_int]),
     "epi_prof_get": (C.c_int, [_CS, C.POINTER(_F64), C.POINTER(_I64)]),
     "epi_prof_reset": (None, []),

@@ -79,9 +79,10 @@ class ProcessedBam:
         self.dev = None         # dict of torch tensors (kept alive for an adopted batch) or None
         self.device = None
         self._batch = None
+        self._keep = None       # owner of the host buffers the numpy columns are views of (producer output, pinned tensors)
 
     @classmethod
-    def from_arrays(cls, xm, off, rname, strand, start, levels=None):
+    def from_arrays(cls, xm, off, rname, strand, start, levels=None, keepalive=None, device=None):
         off = np.ascontiguousarray(off, dtype=np.int64)
         n = off.size - 1
         if n < 0:
@@ -95,7 +96,16 @@ class ProcessedBam:
             raise ValueError("off[n] does not match len(xm)")
         self = cls(n, int(off[-1]) if off.size else 0, levels)
         self.host = dict(xm=xm, off=off, rname=cols[0], strand=cols[1], start=cols[2])
+        self._keep = keepalive
+        self.device = device
         return self
+
+    @classmethod
+    def from_pinned(cls, xm, nbytes, off, rname, strand, start, levels=None, device=None):
+        """Pinned host tensors (torch, CPU): the columns are used in place -- epi_batch_upload recognises page-locked
+        sources and DMAs straight from them (no staging copy)."""
+        return cls.from_arrays(xm.numpy()[:int(nbytes)], off.numpy(), rname.numpy(), strand.numpy(), start.numpy(), levels,
+                               keepalive=(xm, off, rname, strand, start), device=device)
 
     @classmethod
     def from_device(cls, xm, nbytes, off, rname, strand, start, levels=None):
@@ -120,7 +130,7 @@ class ProcessedBam:
                                            C.c_void_p(d["strand"].data_ptr()), C.c_void_p(d["start"].data_ptr()),
                                            self.n, C.byref(h)))
         else:
-            eng = _engine(device)
+            eng = _engine(device if device is not None else self.device)
             self.device = lib.epi_engine_device(eng)
             hst = self.host
             p = lambda a: C.c_void_p(a.ctypes.data) if a.size else None
@@ -137,6 +147,19 @@ class ProcessedBam:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class _TemplatesOwner:
+    """Keeps an epi_templates (epi_preprocess_bam output) alive while numpy views of its buffers are in use."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __del__(self):
+        try:
+            _lib.load().epi_templates_free(C.byref(self.t))
         except Exception:
             pass
 
@@ -170,16 +193,15 @@ def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, h
     if rc != _lib.EPI_OK:
         msg = lib.epi_last_error().decode("utf-8", "replace")
         raise ValueError(msg)                                         # stop(..., call.=FALSE) in the reference
-    try:
-        n = t.n
-        take = lambda ptr, k, dt: np.ctypeslib.as_array(ptr, shape=(max(k, 1),))[:k].astype(dt, copy=True)
-        levels = tuple(t.target_names[i].decode("latin1") for i in range(t.n_targets))
-        bam = ProcessedBam.from_arrays(take(t.xm, t.nbytes, np.uint8), take(t.off, n + 1, np.int64),
-                                       take(t.rname, n, np.int32), take(t.strand, n, np.int32),
-                                       take(t.start, n, np.int32), levels)
-        bam.nrecs, bam.npushed, bam.paired = int(t.nrecs), int(n), bool(t.paired)
-    finally:
-        lib.epi_templates_free(C.byref(t))
+    # the producer's buffers are used in place (xm is pinned when a device is usable: the upload DMAs straight from it);
+    # they are released when the ProcessedBam goes away
+    keep = _TemplatesOwner(t)
+    n = t.n
+    view = lambda ptr, k: np.ctypeslib.as_array(ptr, shape=(max(k, 1),))[:k]
+    levels = tuple(t.target_names[i].decode("latin1") for i in range(t.n_targets))
+    bam = ProcessedBam.from_arrays(view(t.xm, t.nbytes), view(t.off, n + 1), view(t.rname, n), view(t.strand, n),
+                                   view(t.start, n), levels, keepalive=keep)
+    bam.nrecs, bam.npushed, bam.paired, bam.pinned = int(t.nrecs), int(n), bool(t.paired), bool(t.pinned)
     return bam
 
 

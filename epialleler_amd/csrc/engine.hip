@@ -180,8 +180,22 @@ static void parallel_memcpy(void *dst, const void *src, size_t len) {
   for (auto &t : th) t.join();
 }
 
+// true when h_src is page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister, e.g. the producer's
+// epi_templates::xm or a torch pinned tensor): the DMA engine can read it directly
+static bool is_pinned_host(const void *h_src) {
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, h_src) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
 static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t bytes) {
   const size_t chunk = 64u << 20;
+  if (bytes && is_pinned_host(h_src)) {
+    // pinned source (what the producer hands over): no staging copy, hipMemcpyAsync straight from the caller's buffer
+    EPI_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, eng->copy_stream));
+    return EPI_OK;
+  }
   if (!eng->pinned[0]) {
     for (int i = 0; i < 2; i++) {
       EPI_HIP(hipHostMalloc(&eng->pinned[i], chunk, hipHostMallocDefault));
@@ -200,8 +214,7 @@ static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t
     done += len;
     k ^= 1;
   }
-  EPI_HIP(hipStreamSynchronize(eng->copy_stream));
-  return EPI_OK;
+  return EPI_OK;                                           // (the caller synchronises the copy stream once, after all columns)
 }
 
 int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const int32_t *rname,
@@ -238,6 +251,7 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const
       if ((rc = staged_upload(e, b->own_strand.p, strand, (size_t)n * 4))) break;
       if ((rc = staged_upload(e, b->own_start.p, start, (size_t)n * 4))) break;
     }
+    if (hipStreamSynchronize(e->copy_stream) != hipSuccess) { rc = fail(EPI_ERR_HIP, "upload failed: %s", hipGetErrorName(hipGetLastError())); break; }
   } while (0);
   if (rc) { epi_batch_free(b); return rc; }
   b->xm = b->own_xm.as<uint8_t>();

@@ -8,6 +8,7 @@
 // methylated reads (CpG methylated w.p. 0.9, else 0.05; other contexts 0.01),
 // 1 % of cytosine bytes re-labelled with another context.
 #include "common.hpp"
+#include <string.h>
 
 namespace epi {
 
@@ -92,9 +93,76 @@ __global__ __launch_bounds__(256) void k_synth_bytes(SynthGeom g, uint32_t *__re
   xm32[d] = w;
 }
 
+// ---- rows given by the caller (uniform-random starts sorted on device, ragged lengths) -----------------
+// Per-row hashes use the global sorted row id x = row_first + k; every `gap_every`-th template (by hash) carries
+// `gap_len` filler bytes (0xFB) in its middle: two mates that do not meet.
+__global__ __launch_bounds__(256) void k_synth_fill_strand(uint64_t seed, int64_t row_first, int64_t n, int32_t *__restrict__ strand) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) strand[k] = 1 + (int32_t)(hash3(seed, 2, (uint64_t)(row_first + k)) & 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_synth_fill_bytes(SynthGeom g, const int64_t *__restrict__ off, const int32_t *__restrict__ rname,
+                                                           const int32_t *__restrict__ start, int32_t gap_every,
+                                                           uint32_t *__restrict__ xm32, int64_t ndw) {
+  const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (d >= ndw) return;
+  const int64_t total = off[g.n];
+  uint32_t w = 0;
+  int64_t k = -1, k_end = -1, k_off = 0;
+  int32_t c = 0, st = 0, len = 0, g0 = 0;
+  bool hy = false, gap = false;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int64_t f = d * 4 + q;
+    uint32_t byte = 0xFBu;
+    if (f < total) {
+      if (f >= k_end) {                                    // row of byte f: the last k with off[k] <= f
+        int64_t a = k < 0 ? 0 : k + 1, z = g.n;            // (zero-length rows are stepped over)
+        while (z - a > 1) { const int64_t m = (a + z) >> 1; if (off[m] <= f) a = m; else z = m; }
+        k = a;
+        k_off = off[k]; k_end = off[k + 1];
+        len = (int32_t)(k_end - k_off);
+        c = rname[k] - 1; st = start[k];
+        const uint64_t x = (uint64_t)(g.row_first + k);
+        hy = (hash3(g.seed, 3, x) % 10ull) == 0ull;
+        gap = gap_every > 0 && g.gap_len > 0 && (hash3(g.seed, 5, x) % (uint64_t)gap_every) == 0ull;
+        g0 = len / 2 - g.gap_len / 2;
+      }
+      const int32_t i = (int32_t)(f - k_off);
+      if (gap && i >= g0 && i < g0 + g.gap_len) byte = 0xFBu;
+      else { SynthGeom h = g; h.gap_len = 0; byte = synth_byte(h, g.row_first + k, i, c, st, hy); }
+    }
+    w |= byte << (8 * q);
+  }
+  xm32[d] = w;
+}
+
 }  // namespace epi
 
 using namespace epi;
+
+extern "C" int epi_synth_fill_dev(uint64_t seed, int64_t row_first, int64_t n, const int64_t *d_off, const int32_t *d_rname,
+                                  const int32_t *d_start, int64_t nbytes, int32_t gap_every, int32_t gap_len,
+                                  uint8_t *d_xm, int32_t *d_strand, void *stream) {
+  if (n < 0 || row_first < 0 || nbytes < 0 || gap_len < 0 || !d_off) return fail(EPI_ERR_ARG, "epi_synth_fill_dev: bad parameters");
+  if (n > 0 && (!d_xm || !d_rname || !d_start || !d_strand)) return fail(EPI_ERR_ARG, "epi_synth_fill_dev: NULL buffer");
+  if ((reinterpret_cast<uintptr_t>(d_xm) & 3) != 0) return fail(EPI_ERR_ARG, "epi_synth_fill_dev: d_xm must be 4-byte aligned");
+  if (n == 0) return EPI_OK;
+  SynthGeom g;
+  memset(&g, 0, sizeof(g));
+  g.seed = seed; g.row_first = row_first; g.n = n; g.gap_len = gap_len;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_synth_fill_strand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, row_first, n, d_strand);
+  const int64_t ndw = (nbytes + 3) / 4;                    // the caller's buffer is padded to 16 bytes
+  if (ndw > 0) {
+    const int64_t nb = (ndw + 255) / 256;
+    if (nb > 0x7FFFFFFFLL) return fail(EPI_ERR_ARG, "epi_synth_fill_dev: too large for one launch");
+    hipLaunchKernelGGL(k_synth_fill_bytes, dim3((unsigned)nb), dim3(256), 0, s, g, d_off, d_rname, d_start, gap_every,
+                       reinterpret_cast<uint32_t *>(d_xm), ndw);
+  }
+  EPI_HIP(hipGetLastError());
+  return EPI_OK;
+}
 
 extern "C" int epi_synth_generate_dev(const epi_synth_params *p, uint8_t *d_xm, int64_t *d_off, int32_t *d_rname,
                                       int32_t *d_strand, int32_t *d_start, void *stream) {

@@ -76,6 +76,7 @@ class HipShardEngine:
         self.device = torch.device("cuda", self.bam.device)
         self._slab = None
         self._range = {}
+        self.last_exchange_bytes = 0          # bytes this rank handed to the last report's all-reduce(s)
 
     def tile_positions(self):
         return self.lib.epi_tile_positions()
@@ -224,6 +225,8 @@ def sharded_mhl_report(engine, ctx, hmax, hmin, max_ooctx_meth_frac, group=None,
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
     cnt_slab, sum_slab = engine.mhl_accumulate(ctx, hmax, hmin, max_ooctx_meth_frac, keys, owned)
+    engine.last_exchange_bytes = (int(cnt_slab.numel() * cnt_slab.element_size() + sum_slab.numel() * sum_slab.element_size())
+                                  if (world > 1 and keys.size) else 0)
     if world > 1 and keys.size:
         dist.all_reduce(cnt_slab, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(sum_slab, op=dist.ReduceOp.SUM, group=group)
@@ -256,6 +259,7 @@ def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None):
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
     slab = engine.cx_accumulate(pass_, ctx, keys, owned)
+    engine.last_exchange_bytes = int(slab.numel() * slab.element_size()) if (world > 1 and keys.size) else 0
     if world > 1 and keys.size:
         dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=group)      # the one data-path collective
     cols = engine.cx_finish(ctx)                                      # [6, nrow_local] int32

@@ -245,6 +245,14 @@ typedef struct {
 int epi_synth_generate_dev(const epi_synth_params *p, uint8_t *d_xm, int64_t *d_off,
                            int32_t *d_rname, int32_t *d_strand, int32_t *d_start, void *stream);
 
+/* Bytes (and strands) for rows the caller laid out itself -- off/rname/start in device memory, e.g. uniform-random
+ * starts sorted on the device and ragged lengths: the same context track and methylation model, per-row
+ * hashes keyed by the global row id row_first + k; every gap_every-th template (by hash, 0 = none) carries gap_len
+ * filler bytes (0xFB) in its middle.  nbytes = off[n]. */
+int epi_synth_fill_dev(uint64_t seed, int64_t row_first, int64_t n, const int64_t *d_off, const int32_t *d_rname,
+                       const int32_t *d_start, int64_t nbytes, int32_t gap_every, int32_t gap_len,
+                       uint8_t *d_xm, int32_t *d_strand, void *stream);
+
 /* ---- profiling hooks (HIP events around the dominant kernels) ------------ */
 void epi_prof_enable(int on);
 /* name: "cx_tiles", "threshold", "mhl_tiles", ...; returns accumulated ms and launch count since reset */

@@ -81,3 +81,44 @@ def random_templates(rng, n, min_len=0, max_len=400, n_rname=3, span=5000, p_gar
         g = rng.random(nb) < p_garbage
         xm[g] = rng.integers(0, 256, size=int(g.sum())).astype(np.uint8)
     return {"xm": xm, "off": off, "rname": rname, "strand": strand, "start": start}
+
+
+def generate_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None, gap_every=4, gap_len=50):
+    """numpy mirror of epialleler_amd.synth.generate_device_uniform (layout by the same torch code on the CPU, bytes by
+    the same hashes as epi_synth_fill_dev)."""
+    from epialleler_amd import synth
+    n = n_total - row_first if n is None else n
+    rname, start, lens = (t.numpy() for t in synth.uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, "cpu"))
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    nb = int(off[-1])
+    with np.errstate(over="ignore"):
+        row = np.repeat(np.arange(n, dtype=np.int64), lens)
+        i = np.arange(nb, dtype=np.int64) - off[row]
+        x = (row + row_first).astype(U64)
+        c = (rname[row] - 1).astype(U64)
+        pos = (start[row].astype(np.int64) + i).astype(U64)
+        sd = mix64((U64(seed) + (U64(16) + c) * U64(0xD1B54A32D192ED03)) & _M)
+        t = (mix64(sd ^ pos) % U64(1000)).astype(np.int64)
+        code = np.full(nb, 12, np.int64)
+        code[(t >= 760) & (t < 895)] = 10
+        code[(t >= 895) & (t < 955)] = 14
+        code[(t >= 955) & (t < 990)] = 15
+        code[t >= 990] = 13
+        cyt = t >= 760
+        v = hash3(seed, 4, (x << U64(16)) + i.astype(U64))
+        noise = cyt & ((v % U64(100)) == U64(0))
+        nxt = np.where(code == 10, 14, np.where(code == 14, 15, 10))
+        code = np.where(noise, nxt, code)
+        hyper = (hash3(seed, 3, x) % U64(10)) == U64(0)
+        thr = np.where(code == 15, np.where(hyper, 900, 50), 10)
+        meth = cyt & (((v >> U64(20)) % U64(1000)).astype(np.int64) < thr)
+        code = np.where(meth, code - 8, code)
+        byte = (0x10 | code).astype(np.uint8)
+        if gap_every > 0 and gap_len > 0:
+            gapped = (hash3(seed, 5, x) % U64(gap_every)) == U64(0)
+            g0 = lens[row] // 2 - gap_len // 2
+            byte[gapped & (i >= g0) & (i < g0 + gap_len)] = 0xFB
+        xs = np.arange(row_first, row_first + n, dtype=np.int64).astype(U64)
+        strand = (1 + (hash3(seed, 2, xs) & U64(1)).astype(np.int64)).astype(np.int32)
+    return {"xm": byte, "off": off, "rname": rname.astype(np.int32), "strand": strand, "start": start.astype(np.int32)}

@@ -19,12 +19,12 @@ def _window_rows(bam, lo, hi):
             "strand": d["strand"][lo:hi].cpu().numpy(), "start": d["start"][lo:hi].cpu().numpy()}
 
 
-def _check_windows(rep, bam, n, oracle_fn, float_cols=()):
+def _check_windows(rep, bam, n, oracle_fn, float_cols=(), L=300, wrows=20000, starts=None):
     key = rep["rname"].astype(np.int64) * (1 << 33) + rep["pos"].astype(np.int64) * 2 + (rep["strand"] - 1)
     assert np.all(np.diff(key) > 0)                     # reference row order, no duplicates
-    L = 300
-    for lo in (0, n // 3 + 17, n - 20000):              # includes both ends and a chromosome interior
-        hi = lo + 20000
+    del key
+    for lo in (starts or (0, n // 3 + 17, n - wrows)):  # includes both ends and a chromosome interior
+        hi = lo + wrows
         w = _window_rows(bam, lo, hi)
         want = oracle_fn(w)
         # rows of the window are complete only where no read outside [lo,hi) can reach: trim one read length
@@ -37,7 +37,7 @@ def _check_windows(rep, bam, n, oracle_fn, float_cols=()):
             return (k >= ((r0 << 32) + p_lo)) & (k <= ((r1 << 32) + p_hi))
         mw = inner(want)
         mg = inner(rep)
-        assert mw.sum() > 1000
+        assert mw.sum() > 300
         for c in want:
             a, b = rep[c][mg], want[c][mw]
             assert a.shape == b.shape, c
@@ -96,4 +96,82 @@ def test_config5_long_reads_scaled():
     mg = (rep["rname"] == 1) & (rep["pos"] <= lim)
     for c in want:
         assert np.array_equal(rep[c][mg], want[c][mw]), c
+    bam.close()
+
+
+# ---- past 4 GiB of xm: 64-bit byte offsets, 32-bit row-relative arithmetic, block indices of long reads ---------------
+# (the windows at the END of the batch sit behind offsets > 2^32, 2^33, 2^34)
+
+def test_config3_cytosine_report_100M_one_gpu():
+    """BASELINE config 3 on one GPU: 100 M PE150 templates = 30 GB of xm, threshold.reads=TRUE."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 100_000_000
+    bam = synth.generate_device(n_total=n, read_len=300, seed=3)
+    assert bam.nbytes > 2 ** 34
+    c = H.CONTEXT_TO_BASES["CG"]
+    rep = ea.generateCytosineReport(bam, threshold_reads=True)
+    rep2 = ea.generateCytosineReport(bam, threshold_reads=True, as_device=True)
+    for k in rep:
+        assert np.array_equal(rep[k], rep2[k].cpu().numpy())    # deterministic
+    del rep2
+    assert 50_000_000 < rep.nrow < 90_000_000
+    def oracle_fn(w):
+        p = orc.threshold_reads(w["xm"], w["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+        return orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], p, "Z")
+    # rows 14.4 M and 28.7 M are where the byte offset crosses 2^32 and 2^33
+    _check_windows(rep, bam, n, oracle_fn, starts=(0, 14_316_000, 28_632_000, 57_260_000, n - 20000))
+    bam.close()
+
+
+def test_config4_mhl_report_50M():
+    """BASELINE config 4 at full size: 50 M PE150 templates (15 GB), generateMhlReport defaults."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 50_000_000
+    bam = synth.generate_device(n_total=n, read_len=300, seed=9)
+    rep = ea.generateMhlReport(bam)
+    rep2 = ea.generateMhlReport(bam, as_device=True)
+    for k in rep:
+        a, b = rep[k], rep2[k].cpu().numpy()
+        assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b)
+    del rep2
+    _check_windows(rep, bam, n, lambda w: orc.mhl_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], "Zz", 0, 0, 0.1),
+                   float_cols=("length", "lmhl"), starts=(0, 14_316_000, 28_632_500, n - 20000))
+    bam.close()
+
+
+def test_config5_long_reads_12GB():
+    """BASELINE config 5 shape past 4 GiB: 1.2 M templates of 10 kb (12 GB): CX and lMHL, windows from the end."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 1_200_000
+    bam = synth.generate_device(n_total=n, read_len=10000, seed=13)
+    assert bam.nbytes > 2 ** 33
+    rep = ea.generateCytosineReport(bam, threshold_reads=False)
+    _check_windows(rep, bam, n, lambda w: orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], None, "Z"),
+                   L=10000, wrows=1500, starts=(0, 429_000, 859_000, n - 1500))
+    del rep
+    m = ea.generateMhlReport(bam)
+    _check_windows(m, bam, n, lambda w: orc.mhl_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], "Zz", 0, 0, 0.1),
+                   float_cols=("length", "lmhl"), L=10000, wrows=1000, starts=(430_000, n - 1000))
+    bam.close()
+
+
+def test_uniform_stream_cytosine_report():
+    """The SURVEY-8d-conformant stream (uniform-random starts, ragged lengths, gapped templates; bench cfg2u) at 3 M
+    templates: thresholded CG report and lMHL against the oracle on windows."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    n = 3_000_000
+    bam = synth.generate_device_uniform(n_total=n, seed=21)
+    c = H.CONTEXT_TO_BASES["CG"]
+    rep = ea.generateCytosineReport(bam, threshold_reads=True)
+    def oracle_fn(w):
+        p = orc.threshold_reads(w["xm"], w["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+        return orc.cx_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], p, "Z")
+    _check_windows(rep, bam, n, oracle_fn, L=360)
+    m = ea.generateMhlReport(bam)
+    _check_windows(m, bam, n, lambda w: orc.mhl_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], "Zz", 0, 0, 0.1),
+                   float_cols=("length", "lmhl"), L=360)
     bam.close()

@@ -331,6 +331,24 @@ def test_synth_matches_numpy_mirror(ea):
     torch.cuda.synchronize()
 
 
+def test_uniform_synth_matches_numpy_mirror(ea):
+    """The SURVEY-8d-conformant generator (uniform starts sorted, ragged lengths, gapped templates; bench cfg2u)."""
+    from epialleler_amd import synth
+    for kw in (dict(n_total=4000), dict(n_total=9000, n_chr=3, row_first=2500, n=5000, gap_every=2, gap_len=31),
+               dict(n_total=1500, mean_len=120, depth=9, gap_every=0)):
+        bam = synth.generate_device_uniform(**kw)
+        ref = synth_np.generate_uniform(**kw)
+        d = bam.dev
+        assert np.array_equal(d["xm"][:bam.nbytes].cpu().numpy(), ref["xm"])
+        for k in ("off", "rname", "strand", "start"):
+            assert np.array_equal(d[k].cpu().numpy(), ref[k]), k
+        bam.close()
+
+
+def test_uniform_synth_medium_parity(ea):
+    check_all(ea, synth_np.generate_uniform(n_total=20000), contexts=("CG", "CX"))
+
+
 @pytest.mark.parametrize("kw", [dict(n_total=20000, read_len=300), dict(n_total=6000, read_len=300, gap_from=150, gap_len=50),
                                 dict(n_total=300, read_len=10000, n_chr=2)])
 def test_synth_medium_parity(ea, kw):

@@ -140,3 +140,51 @@ def test_rccl_single_rank_slab_roundtrip(tmp_path):
     H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_cx.npz"))), want)
     want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", 0, 0, 0.1)
     H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_mhl.npz"))), want, float_cols=("length", "lmhl"))
+
+
+def _nccl_worker(rank, world, port, outdir):
+    """Real RCCL ranks, one GPU each (needs >= 2 devices): sharded CX and lMHL tables gathered on rank 0."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import epialleler_amd as ea
+    from epialleler_amd import distributed as D
+    for name in ("wgs", "amplicon"):
+        t = _case(name)
+        n = t["off"].size - 1
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        off = t["off"][lo:hi + 1]
+        shard = ea.ProcessedBam.from_arrays(t["xm"][int(off[0]):int(off[-1])], off - off[0], t["rname"][lo:hi],
+                                            t["strand"][lo:hi], t["start"][lo:hi], device=rank)
+        eng = D.HipShardEngine(shard)
+        rep = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True)
+        m = D.sharded_mhl(eng, gather=True)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "nccl_%s_cx.npz" % name), **{k: v.cpu().numpy() for k, v in rep.items()})
+            np.savez(os.path.join(outdir, "nccl_%s_mhl.npz" % name), **{k: v.cpu().numpy() for k, v in m.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_two_gpus(tmp_path):
+    """The nccl (RCCL over xGMI) path with more than one rank; skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs")
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 4)
+    mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    c = H.CONTEXT_TO_BASES["CG"]
+    for name in ("wgs", "amplicon"):
+        t = _case(name)
+        p = orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+        want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, "Z")
+        H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "nccl_%s_cx.npz" % name))), want)
+        wm = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", 0, 0, 0.1)
+        H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "nccl_%s_mhl.npz" % name))), wm, float_cols=("length", "lmhl"))
