@@ -95,6 +95,7 @@ _SIGS = {
                                            C.POINTER(PatternTable)]),
     "epi_pattern_table_free": (None, [C.POINTER(PatternTable)]),
     "epi_batch_cx_report_dev": (C.c_int, [_VP, _VP, _CS, _VP, C.POINTER(_I64)]),
+    "epi_batch_cytosine_report_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _CS, _VP, _VP, C.POINTER(_I64)]),
     "epi_batch_cx_fetch_dev": (C.c_int, [_VP, C.POINTER(_VP), _VP]),
     "epi_batch_cx_fetch_host": (C.c_int, [_VP, C.POINTER(_VP), _VP]),
     "epi_batch_mhl_report_dev": (C.c_int, [_VP, _CS, C.c_int, C.c_int, _F64, _VP, C.POINTER(_I64)]),

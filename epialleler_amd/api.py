@@ -276,6 +276,36 @@ def rcpp_cx_report(df, pass_, ctx, as_device=False):
     return Report(dict(zip(names, cols)), bam.levels)
 
 
+def cytosine_report_fused(df, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
+                          max_ooctx_meth_frac, ctx, as_device=False, return_pass=False):
+    """rcpp_threshold_reads followed by rcpp_cx_report with its result (what generateCytosineReport does with
+    threshold.reads=TRUE, R/generateCytosineReport.R:181-199) as ONE call: epi_batch_cytosine_report_dev decides every
+    read inside the tile kernel, from the bytes it has loaded anyway.  Same table as the two calls."""
+    torch = _torch()
+    lib = _lib.load()
+    bam = _as_bam(df)
+    b = bam.batch()
+    dev = "cuda:%d" % bam.device
+    pass_out = torch.empty(max(bam.n, 1), dtype=torch.int32, device=dev) if return_pass else None
+    nrow = C.c_int64(0)
+    _lib.check(lib.epi_batch_cytosine_report_dev(
+        b, _lib.enc(ctx_meth), _lib.enc(ctx_unmeth), _lib.enc(ooctx_meth), _lib.enc(ooctx_unmeth), int(min_n_ctx),
+        float(min_ctx_meth_frac), float(max_ooctx_meth_frac), _lib.enc(ctx),
+        C.c_void_p(pass_out.data_ptr()) if pass_out is not None else None, _stream(bam.device), C.byref(nrow)))
+    n = nrow.value
+    cols = list(torch.empty((6, n), dtype=torch.int32, device=dev).unbind(0))
+    if n:
+        _lib.check(lib.epi_batch_cx_fetch_dev(b, _ptr_array(cols), _stream(bam.device)))
+    names = ("rname", "strand", "pos", "context", "meth", "unmeth")
+    if not as_device:
+        cols = [c.cpu().numpy() for c in cols]
+    rep = Report(dict(zip(names, cols)), bam.levels)
+    if return_pass:
+        p = pass_out[:bam.n]
+        return rep, (p if as_device else p.cpu().numpy().astype(bool))
+    return rep
+
+
 def rcpp_mhl_report(df, ctx, hmax, hmin, max_ooctx_meth_frac, as_device=False):
     """src/rcpp_mhl_report.cpp:46-228 -> rname,strand,pos,context,coverage (int32), length,lmhl (float64)."""
     torch = _torch()
@@ -358,12 +388,12 @@ def generateCytosineReport(bam, report_file=None, threshold_reads=True, threshol
     report_context = threshold_context if report_context is None else _match_arg(report_context, _CTX_CHOICES, "report.context")
     bam = preprocessBam(bam, **preprocess_args)
     if threshold_reads:
-        c = CONTEXT_TO_BASES[threshold_context]
-        pass_ = rcpp_threshold_reads(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"],
-                                     min_context_sites, min_context_beta, max_outofcontext_beta, as_device=True)
-    else:
-        pass_ = None                            # rep(TRUE, nrow(bam)), :193-195
-    rep = rcpp_cx_report(bam, pass_, CONTEXT_TO_BASES[report_context]["ctx_meth"], as_device=as_device)
+        c = CONTEXT_TO_BASES[threshold_context]   # .thresholdReads + .getCytosineReport (:181-199) in one pass over the bytes
+        rep = cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"],
+                                    min_context_sites, min_context_beta, max_outofcontext_beta,
+                                    CONTEXT_TO_BASES[report_context]["ctx_meth"], as_device=as_device)
+    else:                                       # pass <- rep(TRUE, nrow(bam)), :193-195
+        rep = rcpp_cx_report(bam, None, CONTEXT_TO_BASES[report_context]["ctx_meth"], as_device=as_device)
     if report_file is None:
         return rep
     writeReport(rep, report_file, gzip)

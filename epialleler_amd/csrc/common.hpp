@@ -97,6 +97,9 @@ struct epi_batch {
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
+  int cx_last_np = 0;                          // ... its number of reported contexts and their codes
+  uint32_t cx_last_ctx_of_plane = 0;
+  epi::DevBuf pass_tmp;                        // pass flags when thresholding could not be fused and the caller wants none
   size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)
 
   // state of the last report (for fetch)
@@ -158,5 +161,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {       // sum over
 #endif
 
 inline unsigned ctx_to_idx(unsigned char c) { return ((unsigned(c) + 2u) >> 2) & 15u; }   // src/epialleleR.h:28
+
+// A grid holds fewer than 2^32 threads (a larger one wraps silently): refuse instead.
+inline int check_grid(int64_t blocks, int threads, const char *what) {
+  if (blocks < 0 || blocks > 0x7FFFFFFFLL || blocks * threads >= (1LL << 32))
+    return fail(EPI_ERR_ARG, "%s: batch too large for one launch (%lld workgroups of %d threads)", what, (long long)blocks, threads);
+  return EPI_OK;
+}
+
+// ---- per-read class counting shared by the per-read kernels and the fused CX tile kernel (per_read.hip) ----------
+struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // one byte per code: codes 0-3, 4-7, 8-11, 12-15
+struct ThrParams {                                   // rcpp_threshold_reads.cpp:15-23
+  uint32_t min_n_ctx;
+  double min_ctx_meth_frac, max_ooctx_meth_frac;
+};
+// 2-bit membership fields of up to four class strings in one LUT; false when a class string repeats a letter
+bool make_field_lut(const char *const cls[4], ClassLut *out);
 
 }  // namespace epi

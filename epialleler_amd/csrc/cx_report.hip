@@ -1,30 +1,33 @@
-// rcpp_cx_report (src/rcpp_cx_report.cpp:34-159) on the GPU.
+// rcpp_cx_report (src/rcpp_cx_report.cpp:34-159) on the GPU, optionally with rcpp_threshold_reads
+// (src/rcpp_threshold_reads.cpp:15-74) fused in, i.e. all of generateCytosineReport() in ONE pass over the packed bytes.
 //
-// The reference walks the sorted reads and, per base, emplaces
-// pos -> int[32] into an ordered map, flushing the map through the
-// majority-context rule (spit_results, :58-85) whenever a read starts beyond
-// everything seen so far.  For sorted input the flush timing does not change
-// the result: the output is the per-(rname,pos,strand) counter table pushed
-// through the rule, in (rname, pos, '+' before '-') order.
+// The reference walks the sorted reads and, per base, emplaces pos -> int[32] into an ordered map, flushing the map
+// through the majority-context rule (spit_results, :58-85).  For sorted input the flush timing does not change the
+// result: the output is the per-(rname,pos,strand) counter table pushed through the rule, in (rname, pos, '+' before
+// '-') order.  A row (pos, strand, k) is emitted iff context k is reported and n_k = M_k + m_k > cov/2 (integer half,
+// strict): the counters of one position are disjoint and sum to at most cov, so n_k > cov/2 already excludes '.', and
+// every other context, from winning (:64-71).  Per (pos,strand) the table therefore needs only
+//   * (M, m) of each REPORTED context (one for a CG report, three for CX), and
+//   * cov = bases of rows covering the position, minus skipped codes ('+'/'-'/filler, :123), plus nibble 9 once more
+//     (it IS the reference's coverage slot, :126-127).
 //
-// Here a workgroup owns one tile of T (default 1024) consecutive positions (tiles.hip).
-// Its candidate rows are a contiguous row range; a group of G lanes takes a
-// row, streams the slice of the row that falls inside the tile with coalesced
-// dword loads (all in flight before the first is used) and adds every base into
-// counters in LDS with ds_add_u32: two u16 counters per dword ([strand][4 pairs][T],
-// 32 KiB; tiles with more than 32767 candidate rows never get here, they are "heavy"),
-// or plain u32 [strand][8][T]; lanes of a group walk consecutive positions, so their
-// atomics spread over the banks.
-// Only eight counters per (pos,strand) are ever read by the rule: '.', H, h,
-// X, x, Z, z and "everything else that counts toward coverage" (U/u and any
-// other nibble; nibble 9 counts twice because the reference's coverage slot is
-// slot 9, :126-127).  Coverage is their sum, so ONE LDS atomic per base.
-// After a barrier the same workgroup applies the rule -- candidates first (cells
-// where a reported context has any count, listed per wavefront by ballot ranks),
-// then the rule on the listed cells -- and writes (key, meth, unmeth) in position
-// order into the tile's own slot of the row pool (no atomic; a tile with more rows
-// than a slot takes them from an overflow region).  A scan over per-tile row counts
-// then gives every tile its place in the final, ordered table (k_cx_gather).
+// A workgroup owns one tile of T positions on an absolute grid (tiles.hip); its candidate rows are a contiguous range.
+//  * Loads are POSITION-aligned: lane `sub` of the G lanes of a row loads the dwords that cover tile positions
+//    4k..4k+3 (unaligned global_load_dword; the hardware allows it), so the four bases of a dword land in ONE LDS cell.
+//  * Counters are u8, four positions per dword, (M | m) of a context side by side in one u64: ONE ds_add_u64 per
+//    dword of xm and reported context (issued only by lanes whose dword holds a call) instead of one LDS atomic per
+//    base.  u8 counters are folded into u16 pairs every 192 rows (a row adds at most 1 per position and counter).
+//  * Coverage is a difference array (+1 at the first, -1 behind the last position of a row: two LDS atomics per row,
+//    both strands packed into one dword); skipped / doubled codes go to a second u8 array that is folded into it.
+//  * Fused thresholding (WHOLE = true): the G lanes load the WHOLE row (reads of up to 2.5 kb), count the four
+//    thresholding classes from the same registers (one v_perm LUT lookup per dword, 2-bit fields, DPP group sums),
+//    decide pass/fail as the reference does (IEEE divisions, :43-70) and then add the row's calls -- lower-cased when
+//    it failed (:118,122).  Rows that reach into two tiles are decided twice (same result); the xm bytes come from
+//    HBM once (the second visit is an L2 hit thanks to the XCD-aware tile order).
+// After a barrier the workgroup prefix-sums the coverage array, lists the cells with any call (ballot ranks), applies
+// the rule and writes (key, meth, unmeth) in position order into the tile's slot of the row pool; k_cx_gather places
+// the pool rows in the final table.  Ultra-deep tiles are split over many workgroups through a slab in HBM; tiles
+// shared with other ranks of a sharded run hand over the same slab for the RCCL all-reduce.
 #include "common.hpp"
 #include "tile_common.hpp"
 #include <stdio.h>
@@ -34,187 +37,333 @@
 namespace epi {
 
 constexpr int CX_WG = 512;                    // threads per tile workgroup (8 wavefronts)
+constexpr int CX2_NU = 10;                    // dwords a lane keeps in flight per row
+constexpr int CX_FLUSH_ROWS = 192;            // u8 -> u16 fold interval (multiple of the rows per round for every G)
+constexpr int CX_SLAB_COV = 12;               // slab planes [16][T]: 2*(strand*NP + p) + {0: M, 1: m}; 12, 13: coverage
+                                              // difference array of '+', '-'; 14, 15 unused
 
-struct CxArgs {
-  RowCols c;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+struct Cx2Args {
+  RowCols c;                              // c.pass: external pass vector or null (all TRUE); ignored when fused
+  int64_t xm_cap;                         // readable bytes behind c.xm
   const Tile *tiles;
-  uint32_t ctx_mask;                      // bit k set: context k (2,6,7) is reported
+  ClassLut lut_r;                         // report LUT: byte = [M0 m0 M1 m1 M2 m2 skip dbl] one-hot flags of a code
+  ClassLut lut_t;                         // fused thresholding: 2-bit class fields (make_field_lut)
+  ThrParams thr;
+  uint32_t fill4;                         // 4 x a code without any flag in either LUT (stands in for bytes outside a row)
+  uint32_t ctx_of_plane;                  // byte p = context code (2, 6, 7) of plane p
+  int32_t *pass_out;                      // fused: pass flag of every row (may be null)
   uint32_t *pool_key, *pool_meth, *pool_unmeth;
   uint32_t pool_cap;
   uint32_t *cursor;                       // rows handed out of the overflow region so far (may exceed its size)
   uint32_t slot_rows, ovf_base;           // tile t owns pool rows [t * slot_rows, +slot_rows); larger tiles take
                                           // rows from [ovf_base, pool_cap) through the cursor
   uint32_t *tile_nrow, *tile_base;
-  int32_t *slab;                          // shared-tile counters [slot][16][T]
-  int ablate;                             // timing experiments only (EPIHIP_CX_ABLATE): 1 skip accumulate, 2 skip emit, 4 loads only
-  unsigned long long *diag;               // timing experiments only (EPIHIP_CX_DIAG): per-phase cycle sums of wave 0
+  int32_t *slab;                          // shared-tile slabs [slot][16][T]
   // ultra-deep tiles (amplicon pile-ups) are set aside by k_cx_tiles and split over many workgroups
   int heavy_rows;                         // a tile with more candidate rows than this is "heavy"
   int heavy_chunk;                        // rows per work item of k_cx_heavy
   uint32_t *heavy_count, *heavy_max;      // number of heavy tiles, largest candidate-row count among them
   uint32_t *heavy_list;                   // their tile ids (order of discovery)
-  int32_t *heavy_slab;                    // [heavy tile][16][T] counters summed over the work items
+  int32_t *heavy_slab;                    // [heavy tile][16][T] summed over the work items
 };
 
-// Adds the in-tile slices of the candidate rows into the LDS counters.  G lanes own one row
-// (64/G rows per wavefront step); a lane keeps CX_NU dword loads of its row in flight and the next
-// step's row columns are fetched with them.  (Deeper software pipelines -- bytes one step ahead and
-// columns three on the u32 layout, later two or three whole steps in flight through unconditional
-// buffer loads -- ran no faster: DESIGN.md 4.3.)
-// dwords u = U0..U1-1 of a lane's row slice (dword index sub + u*G), all already loaded
-template <int T, int G, int U0, int U1, bool PK>
-__device__ __forceinline__ void cx_add_range(const uint32_t (&w)[CX_NU], int sub, const RowSlice &cur) {
-  if constexpr (U0 < U1) {
-    if (U0 * G <= cur.tl) cx_add_dword<T, 4 * G * U0, U0 == 0, PK>(w[U0], cur.tl == U0 * G, cur);
-    cx_add_range<T, G, U0 + 1, U1, PK>(w, sub, cur);
+template <int T, int NP> struct Cx2Lds {
+  static constexpr int Q = T / 4;
+  static constexpr int N_NARROW = 2 * NP * Q;    // u64: [strand][plane][Q], low dword = M of 4 positions (u8), high = m
+  static constexpr int N_CORR = 2 * Q;           // u64: [strand][Q], low dword = skipped, high = doubled (u8 x 4)
+  static constexpr int N_WIDE = 2 * NP * T;      // u32: [strand][plane][T] = M | m << 16
+  static constexpr int N_COV = T + 4;            // u32: coverage difference array, '+' in the low half, '-' in the high half;
+                                                 // entry T = "behind the tile"
+  unsigned long long *narrow, *corr;
+  uint32_t *wide, *cov;
+};
+
+// 16-entry byte LUT lookup of the four codes of a dword; pick0 = 0x03020100 or, for a lower-cased read, 0x07060504
+// (every byte takes the codes-8..15 half: c | 8, rcpp_cx_report.cpp:118,122)
+__device__ __forceinline__ uint32_t cx2_lut(uint32_t w, const ClassLut &F, uint32_t pick0) {
+  const uint32_t lo3 = w & 0x07070707u;
+  const uint32_t pick = ((w >> 1) & 0x04040404u) | pick0;
+  return __builtin_amdgcn_perm(__builtin_amdgcn_perm(F.hi1, F.hi0, lo3), __builtin_amdgcn_perm(F.lo1, F.lo0, lo3), pick);
+}
+
+template <int G>
+__device__ __forceinline__ uint32_t cx2_group_sum(uint32_t v) {     // over the G lanes of a row, every lane gets it
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);                  // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);                 // row_half_mirror
+  if (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);    // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// rcpp_threshold_reads.cpp:43-70 on the four class counts of a read
+__device__ __forceinline__ int cx2_threshold(uint32_t n_m, uint32_t n_u, uint32_t o_m, uint32_t o_u, const ThrParams &prm) {
+  int res = 0;
+  if (n_m != 0) {                                           // :43
+    const unsigned n_all = n_m + n_u;
+    if (!(n_all < prm.min_n_ctx)) {                         // :50
+      const double frac = (double)n_m / (double)n_all;      // :52
+      if (!(frac < prm.min_ctx_meth_frac)) {
+        res = 1;
+        if (o_m > 0) {                                      // :59
+          const unsigned o_all = o_m + o_u;
+          const double ofrac = (double)o_m / (double)o_all; // :66
+          if (ofrac > prm.max_ooctx_meth_frac) res = 0;
+        }
+      }
+    }
+  }
+  return res;
+}
+
+// One visit of up to G * CX2_NU position-aligned dwords of a row, starting at dword ks: loads (all in flight before
+// the first is used), then -- WHOLE -- the thresholding decision, then the calls.  `fetch_next` runs between the
+// loads and their first use (the caller fetches the next row's columns there).
+struct Cx2Row {
+  const uint8_t *base;                    // address of tile position 0 in the row's byte string (may lie outside the row)
+  int32_t rel, k0, klast;                 // tile position of byte 0; first / last position-aligned dword of the row
+  uint32_t mask_first, mask_last;         // bytes of those dwords that belong to the row
+  int back, fwd;                          // bytes the first / last dword would reach outside the buffer (edge rows only)
+  int sidx, ps;
+};
+
+template <int T, int G, int NP, bool WHOLE, class F>
+__device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t ks, int32_t kz, int sub, int rcur,
+                                          const Cx2Lds<T, NP> &L, F fetch_next) {
+  constexpr int Q = T / 4;
+  const int32_t kb = ks + sub;                                      // this lane's dwords: kb + u*G
+  const int32_t tl = kz - kb;                                       // dword u is part of the visit iff u*G <= tl
+  uint32_t w[CX2_NU];
+  if (__builtin_expect((g.back | g.fwd) != 0, 0)) {
+#pragma unroll
+    for (int u = 0; u < CX2_NU; u++) {
+      const int32_t k = kb + u * G;
+      uint32_t x = a.fill4;
+      if (u * G <= tl) {
+        const int fb = k == g.k0 ? g.back : 0, ff = k == g.klast ? g.fwd : 0;
+        x = *reinterpret_cast<const u32_unaligned *>(g.base + 4 * (int64_t)k + fb - ff);
+        x = (x << (8 * fb)) >> (8 * ff);
+      }
+      w[u] = x;
+    }
+  } else {
+    const uint8_t *p = g.base + 4 * (int64_t)kb;
+#pragma unroll
+    for (int u = 0; u < CX2_NU; u++)
+      w[u] = u * G <= tl ? *reinterpret_cast<const u32_unaligned *>(p + 4 * u * G) : a.fill4;
+  }
+  fetch_next();
+  // bytes of the first / last dword that belong to neighbouring rows -> a code without flags
+  if (kb == g.k0) w[0] = (w[0] & g.mask_first) | (a.fill4 & ~g.mask_first);
+#pragma unroll
+  for (int u = 0; u < CX2_NU; u++)
+    if (kb + u * G == g.klast) w[u] = (w[u] & g.mask_last) | (a.fill4 & ~g.mask_last);
+
+  if constexpr (WHOLE) {
+    // thresholding classes of the whole row: 2-bit fields, three dwords add field-wise (<= 3), split into even /
+    // odd 4-bit fields (<= 10 over a lane's 10 dwords), summed by v_sad_u8, two counts per word over the group
+    uint32_t E = 0, O = 0;
+#pragma unroll
+    for (int u0 = 0; u0 < CX2_NU; u0 += 3) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int u = u0; u < u0 + 3 && u < CX2_NU; u++) t += cx2_lut(w[u], a.lut_t, 0x03020100u);
+      E += t & 0x33333333u;
+      O += (t >> 2) & 0x33333333u;
+    }
+    const uint32_t c0 = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, 0u), c2 = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, 0u);
+    const uint32_t c1 = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, 0u), c3 = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, 0u);
+    const uint32_t s01 = cx2_group_sum<G>(c0 | (c1 << 16)), s23 = cx2_group_sum<G>(c2 | (c3 << 16));
+    g.ps = cx2_threshold(s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16, a.thr);
+    if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;   // by the tile the row starts in
+  }
+
+  // calls of the reported contexts: one ds_add_u64 per dword and plane, only from lanes that hold a call
+  const uint32_t pick0 = g.ps == 0 ? 0x07060504u : 0x03020100u;     // failed the threshold: lower-cased (:118)
+  unsigned long long *nar = L.narrow + g.sidx * NP * Q + kb;
+  unsigned long long *cor = L.corr + g.sidx * Q + kb;
+#pragma unroll
+  for (int u = 0; u < CX2_NU; u++) {
+    const uint32_t f = cx2_lut(w[u], a.lut_r, pick0);
+    const bool inside = (uint32_t)(kb + u * G) < (uint32_t)Q;        // (slice mode: always)
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const uint32_t lo = (f >> (2 * p)) & 0x01010101u, hi = (f >> (2 * p + 1)) & 0x01010101u;
+      if ((lo | hi) != 0u && inside) atomicAdd(nar + p * Q + u * G, (unsigned long long)lo | ((unsigned long long)hi << 32));
+    }
+    if ((f & 0xC0C0C0C0u) != 0u && inside)
+      atomicAdd(cor + u * G, (unsigned long long)((f >> 6) & 0x01010101u) | ((unsigned long long)((f >> 7) & 0x01010101u) << 32));
   }
 }
 
-template <int T, int G, int WG, bool PK>
-__device__ __forceinline__ void cx_accumulate(const CxArgs &a, const Tile &td, uint32_t *cnt) {
-  constexpr int R = 64 / G;
-  constexpr int NW = WG / 64;
+// Rows [row_lo, row_hi) of the tile into the u8 counters and the coverage array.  G lanes own a row (64/G rows per
+// wavefront step); the next step's row columns are fetched while the current row's bytes are in flight.
+template <int T, int G, int NP, bool WHOLE>
+__device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
+  constexpr int R = 64 / G, NW = CX_WG / 64, Q = T / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
-  int r = td.row_lo + wave * R + grp;
-  RowSlice cur = cx_row_slice<T, G, PK>(a.c, td, r, sub, cnt);
-  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
-    uint32_t w[CX_NU];                                    // every load of the slice is in flight before the first is used
-#pragma unroll
-    for (int u = 0; u < CX_NU; u++) {
-      w[u] = u * G <= cur.tl ? cur.src[u * G] : 0u;
-    }
+  Tile tb = td;
+  tb.row_hi = row_hi;
+  int r = row_lo + wave * R + grp;
+  RowVals v = cx_load_row(a.c, tb, r);
+  for (int rbase = row_lo + wave * R; rbase < row_hi; rbase += NW * R) {
+    const int rcur = r;
     r += NW * R;
-    const RowSlice nxt = cx_row_slice<T, G, PK>(a.c, td, r, sub, cnt);
-    if (a.ablate & 4) {                                   // timing experiment: the loads without the counting
-      uint32_t x = 0;
-#pragma unroll
-      for (int u = 0; u < CX_NU; u++) x ^= w[u];
-      if (x == 0x12345678u) atomicAdd(cnt, 1u);
-      cur = nxt;
-      continue;
+    RowVals nv;
+    bool fetched = false;
+    auto fetch_next = [&]() { if (!fetched) { nv = cx_load_row(a.c, tb, r); fetched = true; } };
+    if (v.ok && v.len > 0) {
+      // geometry: rel = tile position of the row's byte 0 (-Lmax < rel < T); the row's bytes sit in the
+      // position-aligned dwords k0..klast (dword k = tile positions 4k..4k+3)
+      Cx2Row g;
+      g.rel = (int32_t)((uint32_t)v.st - (uint32_t)td.pos0);
+      g.k0 = g.rel >> 2;
+      g.klast = (g.rel + v.len - 1) >> 2;
+      g.base = a.c.xm + (v.o - g.rel);
+      g.mask_first = 0xFFFFFFFFu << (8 * (g.rel & 3));
+      g.mask_last = 0xFFFFFFFFu >> (8 * (3 - ((g.rel + v.len - 1) & 3)));
+      // the first / last dword may start before / end behind the buffer (first and last rows of a batch only)
+      const int64_t a0 = v.o - (g.rel & 3), a1 = v.o - g.rel + 4 * (int64_t)g.klast + 4;
+      g.back = a0 < 0 ? (int)-a0 : 0;
+      g.fwd = a1 > a.xm_cap ? (int)(a1 - a.xm_cap) : 0;
+      g.sidx = v.sd - 1;
+      g.ps = v.ps;
+      if constexpr (WHOLE) {
+        cx2_visit<T, G, NP, true>(a, g, g.k0, g.klast, sub, rcur, L, fetch_next);     // the host made sure the row fits
+      } else {
+        const int32_t ka = g.k0 > 0 ? g.k0 : 0, kz = g.klast < Q - 1 ? g.klast : Q - 1;   // the slice inside the tile
+        for (int32_t ks = ka; ks <= kz; ks += G * CX2_NU) cx2_visit<T, G, NP, false>(a, g, ks, kz, sub, rcur, L, fetch_next);
+      }
+      if (sub == 0) {                                                 // coverage: +1 on the row's positions inside the tile
+        const int32_t ca = g.rel > 0 ? g.rel : 0, cb = g.rel + v.len < T ? g.rel + v.len : T;
+        const uint32_t unit = g.sidx ? 65536u : 1u;
+        if (ca < cb) { atomicAdd(L.cov + ca, unit); atomicAdd(L.cov + cb, 0u - unit); }
+      }
     }
-    cx_add_range<T, G, 0, CX_NU, PK>(w, sub, cur);
-    for (int k = sub + CX_NU * G; k < cur.nd; k += G) {   // slices longer than CX_NU*G dwords (EPIHIP_CX_GROUP overrides)
-      RowSlice t = cur;
-#pragma unroll
-      for (int j = 0; j < 4; j++) t.dst[j] = cur.dst[j] + 4 * (k - sub);
-      cx_add_dword<T, 0, false, PK>(cur.src[k - sub], k == cur.nd - 1, t);
-    }
-    cur = nxt;
+    fetch_next();
+    v = nv;
   }
 }
 
-// The reference's majority rule on one (pos,strand): returns context 2/6/7 or 0 (no row).
-__device__ __forceinline__ int cx_rule(const uint32_t c[8], uint32_t ctx_mask, uint32_t *meth, uint32_t *unmeth) {
-  const uint32_t nH = c[SLOT_H] + c[SLOT_h], nX = c[SLOT_X] + c[SLOT_x], nZ = c[SLOT_Z] + c[SLOT_z];
-  const uint32_t cov = c[SLOT_DOT] + c[SLOT_OTHER] + nH + nX + nZ;
-  if (cov == 0) return 0;                                 // :62
-  const uint32_t half = cov >> 1;                         // :63
-  int k;
-  if (c[SLOT_DOT] > half) return 0;                       // :64
-  else if (nH > half) { k = 2; *meth = c[SLOT_H]; *unmeth = c[SLOT_h]; }   // :65
-  else if (nX > half) { k = 6; *meth = c[SLOT_X]; *unmeth = c[SLOT_x]; }   // :67
-  else if (nZ > half) { k = 7; *meth = c[SLOT_Z]; *unmeth = c[SLOT_z]; }   // :69
-  else return 0;                                          // :71
-  return ((ctx_mask >> k) & 1u) ? k : 0;                  // :72
+// u8 counters -> u16 pairs, skipped / doubled codes -> coverage difference array.  Every cell has one owner thread.
+template <int T, int NP>
+__device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP> &L) {
+  constexpr int Q = T / 4;
+  for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
+    const unsigned long long v = L.narrow[i];
+    if (v == 0ull) continue;
+    L.narrow[i] = 0ull;
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const int sp = i / Q, q = i - sp * Q;
+    uint4 *wd = reinterpret_cast<uint4 *>(L.wide + sp * T + 4 * q);
+    uint4 c = *wd;
+    c.x += (lo & 255u) | ((hi & 255u) << 16);
+    c.y += ((lo >> 8) & 255u) | (((hi >> 8) & 255u) << 16);
+    c.z += ((lo >> 16) & 255u) | (((hi >> 16) & 255u) << 16);
+    c.w += (lo >> 24) | ((hi >> 24) << 16);
+    *wd = c;
+  }
+  for (int i = threadIdx.x; i < 2 * Q; i += CX_WG) {
+    const unsigned long long v = L.corr[i];
+    if (v == 0ull) continue;
+    L.corr[i] = 0ull;
+    const uint32_t sk = (uint32_t)v, db = (uint32_t)(v >> 32);
+    const int s = i / Q, q = i - s * Q;
+    const int32_t unit = s ? 65536 : 1;
+    int32_t prev = 0;                                                 // coverage change of position 4q+j: doubled - skipped
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int32_t d = (int32_t)((db >> (8 * j)) & 255u) - (int32_t)((sk >> (8 * j)) & 255u);
+      if (d != prev) atomicAdd(L.cov + 4 * q + j, (uint32_t)((d - prev) * unit));
+      prev = d;
+    }
+    if (prev != 0) atomicAdd(L.cov + 4 * q + 4, (uint32_t)(-prev * unit));
+  }
 }
 
 // Pool rows for a tile's n output rows.  Every tile has its own slot of slot_rows rows, so the common case needs no
-// atomic: one cursor for all tiles is ~10^5 atomics on one address, served one by one at ~8 ns each, and a workgroup
-// waited on its turn with 32 KiB of LDS in hand (0.13 ms of the 1.22 ms kernel on 10 M templates; with 512-position
-// tiles the cursor alone set the kernel time).  Only tiles with more rows than a slot go to the cursor.
-__device__ __forceinline__ uint32_t cx_pool_reserve(const CxArgs &a, int tile, uint32_t n, bool *fits) {
+// atomic: one cursor for all tiles is ~10^5 atomics on one address, served one by one at ~8 ns each.  Only tiles with
+// more rows than a slot go to the cursor.
+__device__ __forceinline__ uint32_t cx_pool_reserve(const Cx2Args &a, int tile, uint32_t n, bool *fits) {
   if (n <= a.slot_rows) { *fits = true; return (uint32_t)tile * a.slot_rows; }
   const uint32_t o = atomicAdd(a.cursor, n);
   *fits = (uint64_t)a.ovf_base + o + n <= a.pool_cap;
   return a.ovf_base + o;
 }
 
-// Rule + ordered compaction of one tile's u32 counters [16][T] (LDS, or staged from a slab) into the row pool.
-template <int T, int WG>
-__device__ __forceinline__ void cx_emit(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan) {
-  constexpr int PPT = T / WG;                          // consecutive positions per thread
-  static_assert(PPT == 1 || PPT == 2 || PPT == 4, "emit phase layout");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = WG / 64;
-  const int p0 = threadIdx.x * PPT;
-  uint32_t key[2 * PPT], me[2 * PPT], un[2 * PPT];       // statically indexed (fully unrolled): stay in VGPRs
-  bool ok[2 * PPT];
-  int nr = 0;
+// Where the emit phase reads a tile's sums from: LDS (u16 pairs, packed coverage) ...
+template <int T, int NP> struct CxSrcLds {
+  const uint32_t *wide, *cov;             // cov already prefix-summed
+  __device__ __forceinline__ uint32_t any(int sd, int pos) const {
+    uint32_t x = 0;
 #pragma unroll
-  for (int q = 0; q < PPT; q++) {
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      uint32_t c[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = cnt[(s * 8 + k) * T + p0 + q];
-      uint32_t m = 0, u = 0;
-      const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
-      ok[q * 2 + s] = ctx != 0;
-      key[q * 2 + s] = ((uint32_t)(p0 + q) << 4) | ((uint32_t)s << 3) | (uint32_t)ctx;
-      me[q * 2 + s] = m;
-      un[q * 2 + s] = u;
-      nr += ctx != 0;
-    }
+    for (int p = 0; p < NP; p++) x |= wide[(sd * NP + p) * T + pos];
+    return x;
   }
-  // block-wide exclusive scan of nr
-  const uint32_t inc = wave_scan_u32((uint32_t)nr);
+  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *M, uint32_t *m) const {
+    const uint32_t w = wide[(sd * NP + p) * T + pos];
+    *M = w & 0xFFFFu; *m = w >> 16;
+  }
+  __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
+};
+// ... or a slab in HBM (u32 planes; coverage prefix-summed into LDS per strand)
+template <int T, int NP> struct CxSrcSlab {
+  const int32_t *slab;
+  const uint32_t *cov;                    // LDS [2][T], prefix-summed
+  __device__ __forceinline__ uint32_t any(int sd, int pos) const {
+    uint32_t x = 0;
+#pragma unroll
+    for (int p = 0; p < NP; p++) x |= (uint32_t)slab[(2 * (sd * NP + p)) * T + pos] | (uint32_t)slab[(2 * (sd * NP + p) + 1) * T + pos];
+    return x;
+  }
+  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *M, uint32_t *m) const {
+    *M = (uint32_t)slab[(2 * (sd * NP + p)) * T + pos]; *m = (uint32_t)slab[(2 * (sd * NP + p) + 1) * T + pos];
+  }
+  __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { return cov[sd * T + pos]; }
+};
+
+// in-place inclusive prefix sum of arr[0..T) by the whole workgroup (T / CX_WG consecutive entries per thread)
+template <int T>
+__device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
+  constexpr int PPT = T / CX_WG, NW = CX_WG / 64;
+  static_assert(PPT >= 1 && PPT <= 8, "prefix layout");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; j++) x[j] = arr[threadIdx.x * PPT + j];
+#pragma unroll
+  for (int j = 1; j < PPT; j++) x[j] += x[j - 1];
+  const uint32_t inc = wave_scan_u32(x[PPT - 1]);
   if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
-    s_scan[NW] = acc;
-    uint32_t base = 0;
-    bool fits = true;
-    if (acc) base = cx_pool_reserve(a, tile, acc, &fits);
-    s_scan[NW + 1] = base;
-    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
-    a.tile_nrow[tile] = acc;
-    a.tile_base[tile] = base;
-  }
-  __syncthreads();
-  const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
-  const uint32_t ex = inc - (uint32_t)nr + s_scan[wave];
-  if (total != 0xFFFFFFFFu) {
-    uint32_t w = base + ex;
+  uint32_t before = inc - x[PPT - 1];
 #pragma unroll
-    for (int i = 0; i < 2 * PPT; i++) {
-      if (ok[i]) {
-        a.pool_key[w] = key[i];
-        a.pool_meth[w] = me[i];
-        a.pool_unmeth[w] = un[i];
-        w++;
-      }
-    }
-  }
+  for (int w = 0; w < NW; w++) before += w < wave ? s_scan[w] : 0u;
+#pragma unroll
+  for (int j = 0; j < PPT; j++) arr[threadIdx.x * PPT + j] = x[j] + before;
+  __syncthreads();
 }
 
-// Emit for the packed counters.  A wavefront owns T / (WG/64) consecutive positions and walks them in blocks of 32:
-// lanes 0-31 look at the '+' strand of the block, lanes 32-63 at the '-' strand (two conflict-free half-wave reads).
-// Pass 1 only asks whether any reported context has a count at all -- a row needs n_k > cov/2 >= 0 -- and writes
-// the (few) candidates, in key order, to a per-wave list; pass 2 reads the candidates densely, one per lane, and
-// applies the rule.  Ranks come from ballots and popcounts (no shuffle scan); a CG report evaluates the rule for
-// ~4 % of the (pos,strand) cells instead of all of them, a CX report for ~25 %.
-template <int T, int WG>
-__device__ __forceinline__ void cx_emit_packed(const CxArgs &a, int tile, const uint32_t *cnt, uint32_t *s_scan,
-                                               uint16_t *s_list) {
-  constexpr int NW = WG / 64, PW = T / NW, IT = PW / 32;
+// Rule + ordered compaction of one tile into the row pool.  A wavefront owns T / 8 consecutive positions and walks
+// them in blocks of 32: lanes 0-31 look at the '+' strand, lanes 32-63 at the '-' strand.  Pass 1 lists, in key order,
+// the cells with any call of a reported context (a row needs n_k > cov/2 >= 0); pass 2 reads the candidates densely,
+// one per lane, and applies the rule.  Ranks come from ballots and popcounts.
+template <int T, int NP, class SRC>
+__device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &src, uint32_t *s_scan, uint16_t *s_list) {
+  constexpr int NW = CX_WG / 64, PW = T / NW, IT = PW / 32;
   static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l5 = lane & 31, sd = lane >> 5;
   const uint32_t below = (1u << l5) - 1u;
   uint16_t *list = s_list + wave * (2 * PW);
-  const bool rH = (a.ctx_mask >> 2) & 1u, rX = (a.ctx_mask >> 6) & 1u, rZ = (a.ctx_mask >> 7) & 1u;
-  const uint32_t *cs = cnt + sd * 4 * T + wave * PW + l5;
   uint32_t nc = 0;                                        // candidates of this wavefront (uniform)
 #pragma unroll
   for (int i = 0; i < IT; i++) {
-    uint32_t any = 0;
-    if (rH) any |= cs[1 * T + i * 32];
-    if (rX) any |= cs[2 * T + i * 32];
-    if (rZ) any |= cs[3 * T + i * 32];
+    const uint32_t any = src.any(sd, wave * PW + i * 32 + l5);
     const unsigned long long bal = __ballot(any != 0u);
     const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
     // key order inside a block: position first, '+' before '-': lane l precedes lane 32 + l
@@ -234,14 +383,16 @@ __device__ __forceinline__ void cx_emit_packed(const CxArgs &a, int tile, const 
       if (j < nc) {
         const uint32_t id = list[j];
         const int pos = wave * PW + (int)(id >> 6) * 32 + (int)(id & 31u), st = (int)((id >> 5) & 1u);
-        const uint32_t *c0 = cnt + st * 4 * T + pos;
-        uint32_t c[8];
+        const uint32_t half = src.coverage(st, pos) >> 1;                  // :63
+        uint32_t ctx = 0, m = 0, u = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t w = c0[k * T]; c[2 * k] = w & 0xFFFFu; c[2 * k + 1] = w >> 16; }
-        uint32_t m = 0, u = 0;
-        const int ctx = cx_rule(c, a.ctx_mask, &m, &u);
+        for (int p = 0; p < NP; p++) {                                     // :65-71 (at most one context can exceed half)
+          uint32_t M, mm;
+          src.pair(st, p, pos, &M, &mm);
+          if (M + mm > half && ctx == 0) { ctx = (a.ctx_of_plane >> (8 * p)) & 255u; m = M; u = mm; }
+        }
         good = ctx != 0;
-        key[jj] = ((uint32_t)pos << 4) | ((uint32_t)st << 3) | (uint32_t)ctx;
+        key[jj] = ((uint32_t)pos << 4) | ((uint32_t)st << 3) | ctx;
         me[jj] = m;
         un[jj] = u;
       }
@@ -281,6 +432,28 @@ __device__ __forceinline__ void cx_emit_packed(const CxArgs &a, int tile, const 
   }
 }
 
+// Adds a tile's (folded) LDS sums into its dense slab [16][T] in HBM (shared tiles, heavy tiles).  The coverage
+// array goes over un-summed: difference arrays add across work items and ranks like everything else.
+template <int T, int NP>
+__device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP> &L, int32_t *slab) {
+  uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
+  for (int i = threadIdx.x; i < 2 * NP * T; i += CX_WG) {
+    const uint32_t v = L.wide[i];
+    if (!v) continue;
+    const int sp = i / T, p = i - sp * T;
+    if (v & 0xFFFFu) atomicAdd(dst + (2 * sp) * T + p, v & 0xFFFFu);
+    if (v >> 16) atomicAdd(dst + (2 * sp + 1) * T + p, v >> 16);
+  }
+  for (int p = threadIdx.x; p < T; p += CX_WG) {
+    const uint32_t v = L.cov[p];
+    if (!v) continue;
+    const int32_t lo = (int32_t)(int16_t)(v & 0xFFFFu);                // both halves are signed before the prefix sum
+    const int32_t hi = ((int32_t)v - lo) >> 16;
+    if (lo) atomicAdd(dst + CX_SLAB_COV * T + p, (uint32_t)lo);
+    if (hi) atomicAdd(dst + (CX_SLAB_COV + 1) * T + p, (uint32_t)hi);
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
 // Giving XCD x the contiguous tile range [x*chunk, (x+1)*chunk) makes the tiles that run together on
 // an XCD genomic neighbours, so the rows two adjacent tiles both read are served from that L2.
@@ -290,22 +463,54 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
   return (b & 7) * chunk + (b >> 3);
 }
 
-// As many workgroups per CU as LDS and the 2048-thread limit allow (default: packed counters, 32 KiB, four
-// 512-thread workgroups); always 8 waves per SIMD, i.e. a VGPR budget of 64.
-template <int T, int G, int WG, bool PK>
-__global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_tiles(CxArgs a, int ntiles) {
-  constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
-  __shared__ uint32_t s_scan[WG / 64 + 2];
-  __shared__ uint16_t s_list[PK ? 2 * T : 2];              // candidate lists of the packed emit, 2 * T / (WG/64) per wavefront
-  uint32_t *cnt = cnt_raw + kCxGuard;
+// workgroups per CU by LDS (the u8 arrays double as the emit phase's candidate lists) and the 2048-thread limit
+template <int T, int NP> constexpr int cx2_lds_bytes() {
+  return (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 + (Cx2Lds<T, NP>::N_WIDE + Cx2Lds<T, NP>::N_COV) * 4 + 64;
+}
+template <int T, int NP> constexpr int cx2_waves_per_simd() {
+  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP>(), by_thr = 2048 / CX_WG;
+  const int wgs = by_lds < by_thr ? by_lds : by_thr;
+  return (wgs < 1 ? 1 : wgs) * CX_WG / 256;
+}
+
+#define CX2_SHARED(T, NP)                                                                                        \
+  __shared__ __attribute__((aligned(16))) unsigned long long s_u8[Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR]; \
+  __shared__ __attribute__((aligned(16))) uint32_t s_wide[Cx2Lds<T, NP>::N_WIDE];                                \
+  __shared__ __attribute__((aligned(16))) uint32_t s_cov[Cx2Lds<T, NP>::N_COV];                                  \
+  static_assert((Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 >= 4 * T, "the candidate lists reuse the u8 arrays"); \
+  Cx2Lds<T, NP> L;                                                                                               \
+  L.narrow = s_u8; L.corr = s_u8 + Cx2Lds<T, NP>::N_NARROW; L.wide = s_wide; L.cov = s_cov;
+
+template <int T, int NP>
+__device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP> &L) {
+  uint4 *z = reinterpret_cast<uint4 *>(L.narrow);
+  for (int i = threadIdx.x; i < (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) / 2; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  uint4 *y = reinterpret_cast<uint4 *>(L.wide);
+  for (int i = threadIdx.x; i < Cx2Lds<T, NP>::N_WIDE / 4; i += CX_WG) y[i] = make_uint4(0, 0, 0, 0);
+  uint4 *x = reinterpret_cast<uint4 *>(L.cov);
+  for (int i = threadIdx.x; i < Cx2Lds<T, NP>::N_COV / 4; i += CX_WG) x[i] = make_uint4(0, 0, 0, 0);
+}
+
+// rows [row_lo, row_hi) of a tile, folded every CX_FLUSH_ROWS rows; leaves everything in `wide` and `cov`
+template <int T, int G, int NP, bool WHOLE>
+__device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
+  for (int b0 = row_lo; b0 < row_hi; b0 += CX_FLUSH_ROWS) {
+    if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP>(L); __syncthreads(); }
+    cx2_rows<T, G, NP, WHOLE>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
+  }
+  __syncthreads();
+  cx2_flush<T, NP>(L);
+  __syncthreads();
+}
+
+template <int T, int G, int NP, bool WHOLE>
+__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+  CX2_SHARED(T, NP)
+  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-  if (a.diag) t0 = __builtin_amdgcn_s_memtime();
   const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
-  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  cx2_clear<T, NP>(L);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
     if (threadIdx.x == 0) {
@@ -318,81 +523,66 @@ __global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_til
     return;
   }
   __syncthreads();
-  if (a.diag) t1 = __builtin_amdgcn_s_memtime();
-  if (!(a.ablate & 1)) cx_accumulate<T, G, WG, PK>(a, td, cnt);
-  if (a.diag) t2 = __builtin_amdgcn_s_memtime();
-  __syncthreads();
-  if (a.diag) t3 = __builtin_amdgcn_s_memtime();
+  cx2_accumulate<T, G, NP, WHOLE>(a, td, td.row_lo, td.row_hi, L);
   if (td.slot >= 0) {
-    // shared with another rank (or split over several work items): hand the raw counters over
-    cx_dump_slab<T, WG, PK>(cnt, a.slab + (int64_t)td.slot * (kCxPlanes * T));
+    // shared with another rank: hand the raw sums over
+    cx2_dump_slab<T, NP>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
-  if (a.ablate & 2) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
-  if constexpr (PK) cx_emit_packed<T, WG>(a, tile, cnt, s_scan, s_list);
-  else cx_emit<T, WG>(a, tile, cnt, s_scan);
-  if (a.diag && (threadIdx.x & 63) == 0) {      // diagnostic build only: where a wavefront's tile time goes
-    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-    const int w = threadIdx.x >> 6;
-    if (w == 0 || w == WG / 64 - 1) {
-      unsigned long long *d = a.diag + (w == 0 ? 0 : 8);
-      atomicAdd(d + 0, t1 - t0); atomicAdd(d + 1, t2 - t1); atomicAdd(d + 2, t3 - t2); atomicAdd(d + 3, t4 - t3);
-      atomicAdd(d + 4, 1ull);
-    }
-  }
+  cx2_prefix<T>(L.cov, s_scan);
+  CxSrcLds<T, NP> src;
+  src.wide = L.wide; src.cov = L.cov;
+  cx2_emit<T, NP>(a, tile, src, s_scan, reinterpret_cast<uint16_t *>(s_u8));
 }
 
-// One chunk of the candidate rows of one heavy tile: LDS histogram as usual, then added into the tile's
-// dense counter slab in HBM (or straight into its shared slab slot when other ranks contribute too).
-template <int T, int G, int WG, bool PK>
-__global__ __launch_bounds__(WG, (cx_waves_per_simd<T, WG, PK>())) void k_cx_heavy(CxArgs a) {
-  constexpr int NLDS = cx_lds_dwords<T, PK>() + 2 * kCxGuard;
-  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[NLDS];
-  uint32_t *cnt = cnt_raw + kCxGuard;
+// One chunk of the candidate rows of one heavy tile: LDS sums as usual, then added into the tile's slab in HBM (or
+// straight into its shared slab slot when other ranks contribute too).
+template <int T, int G, int NP, bool WHOLE>
+__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_heavy(Cx2Args a) {
+  CX2_SHARED(T, NP)
   const int tile = (int)a.heavy_list[blockIdx.y];
-  Tile td = a.tiles[tile];
+  const Tile td = a.tiles[tile];
   const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
   if (lo >= td.row_hi) return;
-  td.row_lo = lo;
-  if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
-  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < NLDS / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
+  cx2_clear<T, NP>(L);
   __syncthreads();
-  cx_accumulate<T, G, WG, PK>(a, td, cnt);
-  __syncthreads();
-  cx_dump_slab<T, WG, PK>(cnt, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
-                                            : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
+  cx2_accumulate<T, G, NP, WHOLE>(a, td, lo, hi, L);
+  cx2_dump_slab<T, NP>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+                                        : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
 }
 
-// Majority rule + rows for the heavy tiles that are not shared with other ranks.
-template <int T>
-__global__ __launch_bounds__(CX_WG) void k_cx_emit_heavy(CxArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t cnt[kCxPlanes * T];
+// Rule + rows of a tile whose sums sit in a slab: coverage difference arrays -> LDS, prefix sums, emit from HBM.
+template <int T, int NP>
+__device__ __forceinline__ void cx2_emit_from_slab(const Cx2Args &a, int tile, const int32_t *slab) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cov[2 * T];
   __shared__ uint32_t s_scan[CX_WG / 64 + 2];
+  __shared__ uint16_t s_list[2 * T];
+  for (int i = threadIdx.x; i < 2 * T; i += CX_WG) s_cov[i] = (uint32_t)slab[CX_SLAB_COV * T + i];
+  __syncthreads();
+  cx2_prefix<T>(s_cov, s_scan);
+  cx2_prefix<T>(s_cov + T, s_scan);
+  CxSrcSlab<T, NP> src;
+  src.slab = slab; src.cov = s_cov;
+  cx2_emit<T, NP>(a, tile, src, s_scan, s_list);
+}
+
+template <int T, int NP>
+__global__ __launch_bounds__(CX_WG) void k_cx_emit_heavy(Cx2Args a) {
   const int tile = (int)a.heavy_list[blockIdx.x];
-  const Tile td = a.tiles[tile];
-  if (td.slot >= 0) return;                                // emitted after the cross-rank reduce
-  const int32_t *src = a.heavy_slab + (int64_t)blockIdx.x * (kCxPlanes * T);
-  for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
-  __syncthreads();
-  cx_emit<T, CX_WG>(a, tile, cnt, s_scan);
+  if (a.tiles[tile].slot >= 0) return;                     // emitted after the cross-rank reduce
+  cx2_emit_from_slab<T, NP>(a, tile, a.heavy_slab + (int64_t)blockIdx.x * (kCxPlanes * T));
 }
 
-// Emits the shared tiles this rank owns from the (already cross-rank reduced) slab.
-template <int T>
-__global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(CxArgs a, const int32_t *__restrict__ owned,
-                                                        const int32_t *__restrict__ slot_tile) {
-  __shared__ __attribute__((aligned(16))) uint32_t cnt[kCxPlanes * T];
-  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
-  if (!owned[blockIdx.x]) return;                          // one workgroup per shared slot
+// Emits the shared tiles this rank owns from the (already cross-rank reduced) slab: one workgroup per shared slot.
+template <int T, int NP>
+__global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(Cx2Args a, const int32_t *__restrict__ owned,
+                                                         const int32_t *__restrict__ slot_tile) {
+  if (!owned[blockIdx.x]) return;
   const int tile = slot_tile[blockIdx.x];
   if (tile < 0) return;
-  const Tile td = a.tiles[tile];
-  const int32_t *src = a.slab + (int64_t)td.slot * (kCxPlanes * T);
-  for (int i = threadIdx.x; i < kCxPlanes * T; i += CX_WG) cnt[i] = (uint32_t)src[i];
-  __syncthreads();
-  cx_emit<T, CX_WG>(a, tile, cnt, s_scan);
+  cx2_emit_from_slab<T, NP>(a, tile, a.slab + (int64_t)a.tiles[tile].slot * (kCxPlanes * T));
 }
 
 // One wavefront per tile copies the tile's rows from the pool to their place in the final table
@@ -423,96 +613,59 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
   }
 }
 
-// lanes per row: enough that CX_NU dwords per lane cover the longest in-tile slice
-static int pick_cx_group(int32_t max_len, int T) {
-  const char *env = getenv("EPIHIP_CX_GROUP");
-  if (env) { int g = atoi(env); if (g == 8 || g == 16 || g == 32 || g == 64) return g; }
-  const int slice = (max_len < T ? max_len : T) + 3;
-  const int nd = (slice + 3) / 4;
+// ---- host side -------------------------------------------------------------------------------------------------------
+
+// lanes per row: whole rows (fused thresholding) must fit one round of CX2_NU dwords per lane, slices should
+static int pick_cx_group(int32_t max_len, int T, bool whole) {
+  const int span = (whole ? max_len : (max_len < T ? max_len : T)) + 6;   // + misalignment at both ends
+  const int nd = (span + 3) / 4;
   int g = 8;
-  while (g < 64 && g * CX_NU < nd) g <<= 1;   // the whole slice in one round of CX_NU loads per lane
+  while (g < 64 && g * CX2_NU < nd) g <<= 1;
   return g;
 }
+static bool cx_whole_fits(int32_t max_len) { return ((int64_t)max_len + 6 + 3) / 4 <= 64 * CX2_NU; }
 
-// Counter layout: packed u16 pairs (32 KiB of LDS per 1024-position tile: four 512-thread workgroups per CU) unless
-// EPIHIP_CX_PACKED=0 (u32 counters, 64 KiB, two 1024-thread workgroups per CU: 1.52 vs 1.22 ms on config 2).
-static bool cx_packed() {
-  static int pk = -1;
-  if (pk < 0) {
-    pk = 1;
-    if (const char *env = getenv("EPIHIP_CX_PACKED")) pk = atoi(env) != 0;
-  }
-  return pk != 0;
-}
+int cx_tile_positions() { return kTile; }
 
-int cx_tile_positions() {
-  static int t = 0;
-  if (!t) {
-    t = kTile;
-    if (const char *env = getenv("EPIHIP_CX_TILE")) { const int v = atoi(env); if (v == 512 || v == 1024 || v == 2048) t = v; }
-  }
-  return t;
-}
-
-static int cx_workgroup_size() {
-  static int wg = 0;
-  if (!wg) {
-    wg = cx_packed() ? 512 : 1024;              // 32 wavefronts per CU either way (4 x 8 or 2 x 16), measured fastest (profiles/)
-    if (const char *env = getenv("EPIHIP_CX_WG")) { const int v = atoi(env); if (v == 256 || v == 512 || v == 1024) wg = v; }
-  }
-  return wg;
-}
-
-template <int T, int WG, bool PK>
-static void launch_cx_tiles_g(int g, int nt, hipStream_t s, const CxArgs &a) {
-  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
-  switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, WG, PK>), dim3(grid), dim3(WG), 0, s, a, nt); break;
-  }
-}
-
-template <int T, int WG, bool PK>
-static void launch_cx_heavy_g(int g, dim3 grid, hipStream_t s, const CxArgs &a) {
-  switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, WG, PK>), grid, dim3(WG), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, WG, PK>), grid, dim3(WG), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, WG, PK>), grid, dim3(WG), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, WG, PK>), grid, dim3(WG), 0, s, a); break;
-  }
-}
-
-// (T, WG, layout) combinations that are built: the defaults (2048/1024/packed, 1024/1024/u32) and the ones the
-// EPIHIP_CX_* experiment switches reach.  heavy = false: k_cx_tiles over nt tiles; true: k_cx_heavy on `grid` + emit.
-template <int T, int WG, bool PK>
-static void launch_cx_variant(bool heavy, int g, int nt, dim3 grid, hipStream_t s, const CxArgs &a) {
-  if (!heavy) { launch_cx_tiles_g<T, WG, PK>(g, nt, s, a); return; }
-  launch_cx_heavy_g<T, WG, PK>(g, grid, s, a);
-  hipLaunchKernelGGL((k_cx_emit_heavy<T>), dim3(grid.y), dim3(CX_WG), 0, s, a);
-}
-
-static void launch_cx(bool heavy, int T, int g, int nt, dim3 grid, hipStream_t s, const CxArgs &a) {
-  const bool big = cx_workgroup_size() == 1024, pk = cx_packed();
-  if (pk && cx_workgroup_size() == 256) {
-    if (T == 512) launch_cx_variant<512, 256, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 256, true>(heavy, g, nt, grid, s, a);
+template <int T, int NP, bool WHOLE>
+static void launch_cx_g(bool heavy, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+  if (!heavy) {
+    const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
+    switch (g) {
+      case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+    }
     return;
   }
-  if (T == 512) { if (pk) launch_cx_variant<512, 512, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<512, 512, false>(heavy, g, nt, grid, s, a); }
-  else if (T == 2048) {
-    if (pk) { if (big) launch_cx_variant<2048, 1024, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<2048, 512, true>(heavy, g, nt, grid, s, a); }
-    else launch_cx_variant<2048, 1024, false>(heavy, g, nt, grid, s, a);
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
+  }
+  hipLaunchKernelGGL((k_cx_emit_heavy<T, NP>), dim3(grid.y), dim3(CX_WG), 0, s, a);
+}
+
+static void launch_cx(bool heavy, int np, bool whole, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+  constexpr int T = kTile;
+  if (whole) {
+    if (np == 1) launch_cx_g<T, 1, true>(heavy, g, nt, grid, s, a);
+    else if (np == 2) launch_cx_g<T, 2, true>(heavy, g, nt, grid, s, a);
+    else launch_cx_g<T, 3, true>(heavy, g, nt, grid, s, a);
   } else {
-    if (pk) { if (big) launch_cx_variant<1024, 1024, true>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 512, true>(heavy, g, nt, grid, s, a); }
-    else { if (big) launch_cx_variant<1024, 1024, false>(heavy, g, nt, grid, s, a); else launch_cx_variant<1024, 512, false>(heavy, g, nt, grid, s, a); }
+    if (np == 1) launch_cx_g<T, 1, false>(heavy, g, nt, grid, s, a);
+    else if (np == 2) launch_cx_g<T, 2, false>(heavy, g, nt, grid, s, a);
+    else launch_cx_g<T, 3, false>(heavy, g, nt, grid, s, a);
   }
 }
 
-static void launch_cx_emit_slab(int T, int nshared, hipStream_t s, const CxArgs &a, const int32_t *owned, const int32_t *slot_tile) {
-  if (T == 512) hipLaunchKernelGGL((k_cx_emit_slab<512>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
-  else if (T == 2048) hipLaunchKernelGGL((k_cx_emit_slab<2048>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
-  else hipLaunchKernelGGL((k_cx_emit_slab<1024>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
+  constexpr int T = kTile;
+  if (np == 1) hipLaunchKernelGGL((k_cx_emit_slab<T, 1>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else if (np == 2) hipLaunchKernelGGL((k_cx_emit_slab<T, 2>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else hipLaunchKernelGGL((k_cx_emit_slab<T, 3>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
 }
 
 static int ensure_pool(epi_batch *b, size_t rows) {
@@ -524,30 +677,85 @@ static int ensure_pool(epi_batch *b, size_t rows) {
   return EPI_OK;
 }
 
-}  // namespace epi
+// Report LUT for the context string (rcpp_cx_report.cpp:88-91): planes in the rule's order H, X, Z.  Returns the
+// number of reported contexts (0: nothing can be reported).
+static int make_report_lut(uint32_t ctx_mask, ClassLut *lut, uint32_t *ctx_of_plane) {
+  uint32_t f[16] = {0};
+  int np = 0;
+  *ctx_of_plane = 0;
+  for (uint32_t k : {2u, 6u, 7u}) {
+    if (!((ctx_mask >> k) & 1u)) continue;
+    f[k] |= 1u << (2 * np);                                // methylated: M of plane np
+    f[k + 8] |= 1u << (2 * np + 1);                        // unmethylated (or lower-cased): m
+    *ctx_of_plane |= k << (8 * np);
+    np++;
+  }
+  f[11] |= 0x40u;                                          // skipped (:123)
+  f[9] |= 0x80u;                                           // counts twice in the coverage (:126-127)
+  auto pack = [&](int b0) { return f[b0] | (f[b0 + 1] << 8) | (f[b0 + 2] << 16) | (f[b0 + 3] << 24); };
+  lut->lo0 = pack(0); lut->lo1 = pack(4); lut->hi0 = pack(8); lut->hi1 = pack(12);
+  return np;
+}
 
-using namespace epi;
+static uint32_t lut_byte(const ClassLut &l, int code) {
+  const uint32_t w = code < 4 ? l.lo0 : code < 8 ? l.lo1 : code < 12 ? l.hi0 : l.hi1;
+  return (w >> (8 * (code & 3))) & 255u;
+}
 
-extern "C" {
+struct CxThreshold {                      // fused thresholding request (null = use the pass vector)
+  const char *cls[4];
+  ThrParams prm;
+};
 
-int epi_tile_positions(void) { return cx_tile_positions(); }
-
-int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx, void *stream, int64_t *nrow_out) {
-  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_dev: NULL argument");
+// The CX report on a resident batch.  thr != null: thresholding fused into the tile kernel when the batch allows it
+// (class strings without repeated letters, reads of at most ~2.5 kb), else a separate pass of the per-read kernel.
+static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold *thr, int32_t *d_pass_out, const char *ctx,
+                          hipStream_t s, int64_t *nrow_out) {
   *nrow_out = 0;
   b->last_kind = 0;
-  EPI_HIP(hipSetDevice(b->eng->device));
-  hipStream_t s = pick_stream(b, stream);
-
   uint32_t ctx_mask = 0;                                   // rcpp_cx_report.cpp:88-91
   for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
 
-  const int T = cx_tile_positions();
+  constexpr int T = kTile;
   RowStats st;
   int32_t nt = 0;
   EPI_TRY(build_tiles(b, s, T, &st, &nt));
   b->last_ntiles = nt;
-  if (nt == 0) { b->last_kind = 1; b->last_nrow = 0; return EPI_OK; }
+
+  Cx2Args a;
+  memset(&a, 0, sizeof(a));
+  const int np = make_report_lut(ctx_mask, &a.lut_r, &a.ctx_of_plane);
+  a.fill4 = 0x0C0C0C0Cu;                                   // '.': never a call, never skipped, also when lower-cased
+  bool whole = false;
+  DevBuf *own_pass = nullptr;
+  if (thr) {
+    ClassLut ft;
+    int fill = -1;
+    if (make_field_lut(thr->cls, &ft) && cx_whole_fits(st.max_len)) {
+      for (int c : {12, 8, 0, 4})                          // a code outside every class whose report flags are empty either way
+        if (lut_byte(ft, c) == 0 && lut_byte(a.lut_r, c) == 0 && lut_byte(a.lut_r, c | 8) == 0) { fill = c; break; }
+    }
+    if (fill >= 0 && nt > 0 && np > 0) {
+      whole = true;
+      a.lut_t = ft;
+      a.thr = thr->prm;
+      a.fill4 = 0x01010101u * (uint32_t)fill;
+      a.pass_out = d_pass_out;
+    } else if (b->n > 0) {
+      // not fusable: the per-read kernel decides first (into the caller's buffer, or a scratch column)
+      int32_t *dst = d_pass_out;
+      if (!dst) { EPI_TRY(b->pass_tmp.ensure((size_t)b->n * 4)); dst = b->pass_tmp.as<int32_t>(); own_pass = &b->pass_tmp; }
+      EPI_TRY(epi_batch_threshold_reads_dev(b, thr->cls[0], thr->cls[1], thr->cls[2] ? thr->cls[2] : "", thr->cls[3] ? thr->cls[3] : "",
+                                            thr->prm.min_n_ctx, thr->prm.min_ctx_meth_frac, thr->prm.max_ooctx_meth_frac, dst, s));
+      d_pass = dst;
+    }
+  }
+  (void)own_pass;
+  if (nt == 0 || np == 0) {                                // no rows, or a context string without H/X/Z: an empty table
+    if (nt > 0) { /* tiles exist but nothing is reported */ }
+    b->last_kind = 1; b->last_nrow = 0; b->last_ntiles = 0;
+    return EPI_OK;
+  }
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
@@ -561,7 +769,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   uint32_t &slot_state = (ctx_mask & ~(1u << 7)) ? b->cx_slot_wide : b->cx_slot_cg;
   if (!slot_state) slot_state = (ctx_mask & ~(1u << 7)) ? (uint32_t)(3 * T) / 4 : (uint32_t)T / 8;
   uint32_t slot = slot_state > (uint32_t)(2 * T) ? (uint32_t)(2 * T) : slot_state;
-  if (const char *env = getenv("EPIHIP_CX_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }
+  if (const char *env = getenv("EPIHIP_CX_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }   // test hook
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
   size_t ovf_base = (size_t)nt * slot;
   for (;;) {
@@ -574,28 +782,19 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     slot = 0;                                              // the slots do not fit in device memory: every tile through the
     ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
-  const int grp = pick_cx_group(st.max_len, T);
+  const int grp = pick_cx_group(st.max_len, T, whole);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
-  CxArgs a;
-  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = d_pass;
+  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = whole ? nullptr : d_pass;
+  a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
   a.tiles = b->tiles.as<Tile>();
-  a.ctx_mask = ctx_mask;
   a.cursor = cursor;
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
   a.slab = b->d_slab;
-  a.ablate = 0;
-  if (const char *env = getenv("EPIHIP_CX_ABLATE")) a.ablate = atoi(env);
-  a.diag = nullptr;
-  if (getenv("EPIHIP_CX_DIAG")) {
-    EPI_TRY(b->diag.ensure(256));
-    a.diag = b->diag.as<unsigned long long>();
-    EPI_HIP(hipMemsetAsync(a.diag, 0, 128, s));
-  }
   a.heavy_rows = 16384;
-  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
-  if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // packed u16 counters: a base adds at most 2
+  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }   // test hook
+  if (a.heavy_rows > 16384) a.heavy_rows = 16384;          // u16 pairs and the packed coverage halves: a base adds at most 2
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
   a.heavy_list = b->heavy_list.as<uint32_t>();
@@ -606,6 +805,9 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
   a.ovf_base = (uint32_t)ovf_base;
   b->cx_last_slot = slot;
   b->cx_last_ovf = (uint32_t)ovf_base;
+  b->cx_last_np = np;
+  b->cx_last_ctx_of_plane = a.ctx_of_plane;
+  EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, CX_WG, "CX tile kernel"));
   uint32_t used_total[2] = {0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
@@ -617,7 +819,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
       EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     }
     prof_begin("cx_tiles", s);
-    launch_cx(false, T, grp, nt, dim3(1), s, a);
+    launch_cx(false, np, whole, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
@@ -631,7 +833,7 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
       prof_begin("cx_heavy", s);
-      launch_cx(true, T, grp, nt, dim3(nchunks, nheavy), s, a);
+      launch_cx(true, np, whole, grp, nt, dim3(nchunks, nheavy), s, a);
       prof_end("cx_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -645,21 +847,38 @@ int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx
     if (nshared > 0)   // the rerun adds into the slab again
       EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * T * 4, s));
   }
-  if (a.diag) {
-    unsigned long long h[16];
-    EPI_HIP(hipMemcpy(h, a.diag, 128, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 2; k++)
-      if (h[8 * k + 4])
-        fprintf(stderr, "[cx diag wave %s] tiles %llu  cycles/tile: head+clear %.0f  accumulate %.0f  barrier %.0f  emit %.0f\n",
-                k ? "last" : "0", h[8 * k + 4], (double)h[8 * k] / h[8 * k + 4], (double)h[8 * k + 1] / h[8 * k + 4],
-                (double)h[8 * k + 2] / h[8 * k + 4], (double)h[8 * k + 3] / h[8 * k + 4]);
-  }
   if (used_total[0] > used_total[1] / 8 && slot_state < (uint32_t)(2 * T)) slot_state *= 2;   // too many tiles outgrew their slot
   if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
   b->last_kind = 1;
   b->last_nrow = used_total[1];
   *nrow_out = used_total[1];
   return EPI_OK;
+}
+
+}  // namespace epi
+
+using namespace epi;
+
+extern "C" {
+
+int epi_tile_positions(void) { return cx_tile_positions(); }
+
+int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx, void *stream, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_dev: NULL argument");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  return cx_report_impl(b, d_pass, nullptr, nullptr, ctx, pick_stream(b, stream), nrow_out);
+}
+
+int epi_batch_cytosine_report_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                                  const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                                  double max_ooctx_meth_frac, const char *ctx, int32_t *d_pass_out, void *stream,
+                                  int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out || !ctx_meth || !ctx_unmeth) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report_dev: NULL argument");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  CxThreshold t;
+  t.cls[0] = ctx_meth; t.cls[1] = ctx_unmeth; t.cls[2] = ooctx_meth ? ooctx_meth : ""; t.cls[3] = ooctx_unmeth ? ooctx_unmeth : "";
+  t.prm.min_n_ctx = min_n_ctx; t.prm.min_ctx_meth_frac = min_ctx_meth_frac; t.prm.max_ooctx_meth_frac = max_ooctx_meth_frac;
+  return cx_report_impl(b, nullptr, &t, d_pass_out, ctx, pick_stream(b, stream), nrow_out);
 }
 
 // Second half of a sharded report: the slab has been sum-reduced across ranks;
@@ -670,13 +889,11 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   const int32_t nt = b->last_ntiles;
-  uint32_t ctx_mask = 0;
-  for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
-  CxArgs a;
+  Cx2Args a;
   memset(&a, 0, sizeof(a));
   a.tiles = b->tiles.as<Tile>();
-  a.ctx_mask = ctx_mask;
+  a.ctx_of_plane = b->cx_last_ctx_of_plane;
   a.cursor = cursor;
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
@@ -687,14 +904,14 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
   a.slot_rows = b->cx_last_slot;
   a.ovf_base = b->cx_last_ovf;
-  launch_cx_emit_slab(cx_tile_positions(), (int)b->shared_keys.size(), s, a, b->d_shared_owned.as<int32_t>(),
+  launch_cx_emit_slab(b->cx_last_np, (int)b->shared_keys.size(), s, a, b->d_shared_owned.as<int32_t>(),
                       b->d_slot_tile.as<int32_t>());
   EPI_HIP(hipGetLastError());
   uint32_t *d_total = b->misc.as<uint32_t>() + 2;
   EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
   uint32_t ut[2] = {0, 0};                                  // {overflow rows handed out, total rows}: one sync
   EPI_TRY(read_scalars(b, s, cursor, 8, ut));
-  // cannot overflow: epi_batch_cx_report_dev kept 2*kTile rows per shared tile free
+  // cannot overflow: the first half kept 2*kTile rows per shared tile free
   if ((size_t)a.ovf_base + ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
   const uint32_t total = ut[1];
   b->last_kind = 1;
@@ -764,10 +981,12 @@ int epi_batch_cx_fetch_dev(epi_batch *b, int32_t *const d_cols[6], void *stream)
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   const unsigned nb = (unsigned)((b->last_ntiles + 3) / 4);
+  prof_begin("gather", s);
   hipLaunchKernelGGL(k_cx_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
                      b->tile_nrow.as<uint32_t>(), b->tile_base.as<uint32_t>(), b->last_ntiles, b->pool_key.as<uint32_t>(),
                      b->pool_a.as<uint32_t>(), b->pool_b.as<uint32_t>(), d_cols[0], d_cols[1], d_cols[2], d_cols[3],
                      d_cols[4], d_cols[5]);
+  prof_end("gather", s);
   EPI_HIP(hipGetLastError());
   return EPI_OK;
 }

@@ -24,13 +24,7 @@ namespace epi {
 #endif
 constexpr int PR_UN = EPI_PR_UN;   // 16-byte loads a lane keeps in flight
 
-struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // weight bytes for codes 0-3, 4-7, 8-11, 12-15
-struct Luts { ClassLut c[4]; };
-
-struct ThrParams {
-  uint32_t min_n_ctx;
-  double min_ctx_meth_frac, max_ooctx_meth_frac;
-};
+struct Luts { ClassLut c[4]; };                     // weight bytes per class (ClassLut, ThrParams: common.hpp)
 
 static int make_lut(const char *s, ClassLut *out) {
   unsigned w[16] = {0};
@@ -309,7 +303,7 @@ __global__ __launch_bounds__(256, (pw_waves<RPG>())) void k_per_read_wide(const 
 }
 
 // 2-bit membership fields of up to four classes in one LUT; false when a class string repeats a letter
-static bool make_field_lut(const char *const cls[4], ClassLut *out) {
+bool make_field_lut(const char *const cls[4], ClassLut *out) {
   unsigned f[16] = {0};
   for (int k = 0; k < 4; k++) {
     unsigned w[16] = {0};

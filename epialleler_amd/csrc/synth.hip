@@ -22,6 +22,8 @@ __host__ __device__ __forceinline__ uint64_t hash3(uint64_t seed, uint64_t strea
   return mix64(mix64(seed + stream * 0xD1B54A32D192ED03ull) ^ idx);
 }
 
+constexpr int64_t kSynthChunk = 1LL << 30;   // dwords per launch of the byte kernels
+
 struct SynthGeom {
   uint64_t seed;
   int64_t n_total, row_first, n;
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256) void k_synth_meta(SynthGeom g, int64_t *__rest
 }
 
 // one thread per 4 output bytes (one dword store)
-__global__ __launch_bounds__(256) void k_synth_bytes(SynthGeom g, uint32_t *__restrict__ xm32, int64_t ndw) {
-  const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_synth_bytes(SynthGeom g, uint32_t *__restrict__ xm32, int64_t d0, int64_t ndw) {
+  const int64_t d = d0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (d >= ndw) return;
   const int64_t total = g.n * (int64_t)g.L;
   uint32_t w = 0;
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(256) void k_synth_fill_strand(uint64_t seed, int64_
 
 __global__ __launch_bounds__(256) void k_synth_fill_bytes(SynthGeom g, const int64_t *__restrict__ off, const int32_t *__restrict__ rname,
                                                            const int32_t *__restrict__ start, int32_t gap_every,
-                                                           uint32_t *__restrict__ xm32, int64_t ndw) {
-  const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                           uint32_t *__restrict__ xm32, int64_t d0, int64_t ndw) {
+  const int64_t d = d0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (d >= ndw) return;
   const int64_t total = off[g.n];
   uint32_t w = 0;
@@ -154,11 +156,10 @@ extern "C" int epi_synth_fill_dev(uint64_t seed, int64_t row_first, int64_t n, c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_synth_fill_strand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, row_first, n, d_strand);
   const int64_t ndw = (nbytes + 3) / 4;                    // the caller's buffer is padded to 16 bytes
-  if (ndw > 0) {
-    const int64_t nb = (ndw + 255) / 256;
-    if (nb > 0x7FFFFFFFLL) return fail(EPI_ERR_ARG, "epi_synth_fill_dev: too large for one launch");
-    hipLaunchKernelGGL(k_synth_fill_bytes, dim3((unsigned)nb), dim3(256), 0, s, g, d_off, d_rname, d_start, gap_every,
-                       reinterpret_cast<uint32_t *>(d_xm), ndw);
+  for (int64_t d0 = 0; d0 < ndw; d0 += kSynthChunk) {
+    const int64_t cnt = ndw - d0 < kSynthChunk ? ndw - d0 : kSynthChunk;
+    hipLaunchKernelGGL(k_synth_fill_bytes, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, g, d_off, d_rname, d_start, gap_every,
+                       reinterpret_cast<uint32_t *>(d_xm), d0, ndw);
   }
   EPI_HIP(hipGetLastError());
   return EPI_OK;
@@ -186,10 +187,11 @@ extern "C" int epi_synth_generate_dev(const epi_synth_params *p, uint8_t *d_xm, 
   const unsigned nbm = (unsigned)((p->n + 1 + 255) / 256);
   hipLaunchKernelGGL(k_synth_meta, dim3(nbm), dim3(256), 0, s, g, d_off, d_rname, d_strand, d_start);
   const int64_t ndw = (p->n * (int64_t)p->read_len + 3) / 4;   // caller's buffer is padded to 16 bytes
-  if (ndw > 0) {
-    const int64_t nb = (ndw + 255) / 256;
-    if (nb > 0x7FFFFFFFLL) return fail(EPI_ERR_ARG, "epi_synth_generate_dev: too large for one launch");
-    hipLaunchKernelGGL(k_synth_bytes, dim3((unsigned)nb), dim3(256), 0, s, g, reinterpret_cast<uint32_t *>(d_xm), ndw);
+  // a grid holds fewer than 2^32 threads: 2^30 dwords per launch (a 100 M x 300 B batch is 7.5e9 dwords; one launch
+  // of that size silently wrapped and left everything past 12.8 GB unwritten -- found by the 30 GB full-size test)
+  for (int64_t d0 = 0; d0 < ndw; d0 += kSynthChunk) {
+    const int64_t cnt = ndw - d0 < kSynthChunk ? ndw - d0 : kSynthChunk;
+    hipLaunchKernelGGL(k_synth_bytes, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, g, reinterpret_cast<uint32_t *>(d_xm), d0, ndw);
   }
   EPI_HIP(hipGetLastError());
   return EPI_OK;

@@ -95,7 +95,7 @@ class HipShardEngine:
         return rcpp_threshold_reads(self.bam, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n, min_frac,
                                     max_oo, as_device=True)
 
-    def cx_accumulate(self, pass_, ctx, keys, owned):
+    def _attach_cx_slab(self, keys, owned):
         torch = self.torch
         T = self.tile_positions()
         want = max(keys.size, 1) * 16 * T
@@ -110,12 +110,27 @@ class HipShardEngine:
             C.c_void_p(owned.ctypes.data) if keys.size else None, int(keys.size),
             C.c_void_p(self._slab.data_ptr()) if keys.size else None))
         self._nshared = int(keys.size)
+        return self._slab
+
+    def cx_accumulate(self, pass_, ctx, keys, owned):
+        self._attach_cx_slab(keys, owned)
+        self._nshared = int(keys.size)
         nrow = C.c_int64(0)
         _lib.check(self.lib.epi_batch_cx_report_dev(
             self.h, C.c_void_p(pass_.data_ptr()) if pass_ is not None and self.bam.n else None,
             _lib.enc(ctx), _stream(self.bam.device), C.byref(nrow)))
         self._nrow = nrow.value
         return self._slab
+
+    def cx_accumulate_fused(self, thr, ctx, keys, owned):
+        """cx_accumulate with the thresholding (thr = the seven rcpp_threshold_reads arguments) done inside the tile kernel."""
+        slab = self._attach_cx_slab(keys, owned)
+        nrow = C.c_int64(0)
+        _lib.check(self.lib.epi_batch_cytosine_report_dev(
+            self.h, _lib.enc(thr[0]), _lib.enc(thr[1]), _lib.enc(thr[2]), _lib.enc(thr[3]), int(thr[4]), float(thr[5]),
+            float(thr[6]), _lib.enc(ctx), None, _stream(self.bam.device), C.byref(nrow)))
+        self._nrow = nrow.value
+        return slab
 
     def cx_finish(self, ctx):
         torch = self.torch
@@ -249,16 +264,22 @@ def sharded_mhl(engine, haplotype_context="CG", max_haplotype_window=0, min_hapl
                               max_outofcontext_beta, group, gather, levels)
 
 
-def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None):
+def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None, threshold=None):
     """rcpp_cx_report over row-range shards.  Returns the full Report on rank 0 (None elsewhere)
-    when gather=True, else this rank's rows (rank order = table order)."""
+    when gather=True, else this rank's rows (rank order = table order).  threshold = the seven
+    rcpp_threshold_reads arguments: thresholding is then done inside the tile kernel (pass_ is ignored)."""
     import torch
     import torch.distributed as dist
     ranges, world, rank = _exchange_ranges(engine, "cx", group)
     dev = engine.device
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
-    slab = engine.cx_accumulate(pass_, ctx, keys, owned)
+    if threshold is not None and hasattr(engine, "cx_accumulate_fused"):
+        slab = engine.cx_accumulate_fused(threshold, ctx, keys, owned)
+    else:
+        if threshold is not None:
+            pass_ = engine.threshold(*threshold)
+        slab = engine.cx_accumulate(pass_, ctx, keys, owned)
     engine.last_exchange_bytes = int(slab.numel() * slab.element_size()) if (world > 1 and keys.size) else 0
     if world > 1 and keys.size:
         dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=group)      # the one data-path collective
@@ -293,9 +314,9 @@ def sharded_cytosine_report(engine, threshold_reads=True, threshold_context="CG"
                             group=None, gather=True, levels=None):
     """generateCytosineReport() over shards (R/generateCytosineReport.R:164-208)."""
     report_context = report_context or threshold_context
-    pass_ = None
+    thr = None
     if threshold_reads:
         c = CONTEXT_TO_BASES[threshold_context]
-        pass_ = engine.threshold(c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"],
-                                 min_context_sites, min_context_beta, max_outofcontext_beta)
-    return sharded_cx_report(engine, pass_, CONTEXT_TO_BASES[report_context]["ctx_meth"], group, gather, levels)
+        thr = (c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], min_context_sites, min_context_beta,
+               max_outofcontext_beta)
+    return sharded_cx_report(engine, None, CONTEXT_TO_BASES[report_context]["ctx_meth"], group, gather, levels, threshold=thr)

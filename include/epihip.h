@@ -178,6 +178,17 @@ int epi_batch_match_target_dev(epi_batch *b, const int32_t *d_bed_chr, const int
  *     length nrow in device (fetch_dev, async) or host (fetch_host) memory. */
 int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass /* NULL = all TRUE */,
                             const char *ctx, void *stream, int64_t *nrow_out);
+/* generateCytosineReport(threshold.reads=TRUE) in one call (R/generateCytosineReport.R:181-199: .thresholdReads, then
+ * .getCytosineReport with its result): the same table as epi_batch_threshold_reads_dev followed by
+ * epi_batch_cx_report_dev, but the bytes are read from HBM once -- the tile kernel counts the thresholding classes of
+ * a read from the registers it already holds and lower-cases the read's calls itself (rcpp_threshold_reads.cpp:28-71,
+ * rcpp_cx_report.cpp:118).  Fused for reads of up to ~2.5 kb and class strings without repeated letters; other
+ * batches run the two kernels one after the other (same results).  d_pass_out (optional, [n]) receives the pass
+ * flags.  Continue with epi_batch_cx_fetch_* (or epi_batch_cx_finish_shared) as after epi_batch_cx_report_dev. */
+int epi_batch_cytosine_report_dev(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                                  const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                                  double max_ooctx_meth_frac, const char *ctx, int32_t *d_pass_out /* may be NULL */,
+                                  void *stream, int64_t *nrow_out);
 int epi_batch_cx_fetch_dev(epi_batch *b, int32_t *const d_cols[6], void *stream);
 int epi_batch_cx_fetch_host(epi_batch *b, int32_t *const h_cols[6], void *stream);
 

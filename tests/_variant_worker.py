@@ -30,10 +30,15 @@ def main():
         try:
             c = H.CONTEXT_TO_BASES["CG"]
             p = orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
-            for ctx, pv in (("Z", None), ("ZXH", p)):
+            for ctx, pv in (("Z", None), ("ZXH", p), ("ZX", p)):
                 got = ea.rcpp_cx_report(bam, pv, ctx)
                 want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], pv, ctx)
                 H.assert_reports_equal(dict(got), want)
+            for ctx in ("Z", "ZXH"):                                      # thresholding fused into the tile kernel
+                got, gp = ea.cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1,
+                                                   ctx, return_pass=True)
+                assert np.array_equal(gp.astype(np.int32), p)
+                H.assert_reports_equal(dict(got), orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, ctx))
             for hmax, hmin, moo in ((0, 0, 0.1), (3, 2, 1.0)):
                 got = ea.rcpp_mhl_report(bam, "Zz", hmax, hmin, moo)
                 want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, hmin, moo)

@@ -52,6 +52,13 @@ def check_all(ea, t, pass_variants=True, mhl=True, contexts=ALL_CTX):
                 got = ea.rcpp_cx_report(bam, p, c["ctx_meth"])
                 want_r = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, c["ctx_meth"])
                 H.assert_reports_equal(dict(got), want_r)
+            # thresholding fused into the tile kernel (generateCytosineReport's default path): same table, same flags
+            for rctx in (ctx, "CX" if ctx == "CG" else "CG"):
+                letters = C2B[rctx]["ctx_meth"]
+                got, gp = ea.cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1,
+                                                   letters, return_pass=True)
+                assert np.array_equal(gp.astype(np.int32), want), ("fused pass", ctx)
+                H.assert_reports_equal(dict(got), orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], want, letters))
             if mhl:
                 for hmax, hmin, moo in ((0, 0, 0.1), (1, 0, 0.1), (3, 2, 1.0)):
                     got = ea.rcpp_mhl_report(bam, c["ctx_meth"] + c["ctx_unmeth"], hmax, hmin, moo)

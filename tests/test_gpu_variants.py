@@ -1,6 +1,5 @@
-"""The CX tile kernel is built in several (tile size, workgroup size, counter layout) variants; the default
-is the measured-fastest one, the others stay reachable through EPIHIP_CX_* for A/B runs.  Every variant must
-give the oracle's table."""
+"""Test hooks that steer the kernels onto their rarely taken paths (heavy-tile split, pool-slot overflow, the
+alternative lMHL layouts).  None of them changes a result: every setting must give the oracle's table."""
 import os
 import subprocess
 import sys
@@ -13,13 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("env", [
-    {},                                                                  # default: packed u16 counters, T=1024, 512 threads
-    {"EPIHIP_CX_PACKED": "0"},                                           # u32 counters, 1024 threads
-    {"EPIHIP_CX_PACKED": "0", "EPIHIP_CX_TILE": "2048"},
-    {"EPIHIP_CX_TILE": "2048", "EPIHIP_CX_WG": "1024"},
-    {"EPIHIP_CX_TILE": "512", "EPIHIP_CX_WG": "256"},
-    {"EPIHIP_CX_GROUP": "16", "EPIHIP_HEAVY_ROWS": "500"},
-    {"EPIHIP_CX_PACKED": "0", "EPIHIP_CX_GROUP": "64", "EPIHIP_HEAVY_ROWS": "500"},
+    {},                                                                  # defaults
+    {"EPIHIP_HEAVY_ROWS": "500"},                                        # pile-ups split over many workgroups (slabs in HBM)
+    {"EPIHIP_HEAVY_ROWS": "100"},                                        # ... in chunks smaller than the u8 fold interval
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot
     {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
