@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libepihip.so")
+LIB_PATH = os.environ.get("EPIHIP_LIB") or os.path.join(CSRC, "libepihip.so")   # EPIHIP_LIB: a development build
 
 EPI_OK, EPI_ERR_ARG, EPI_ERR_HIP, EPI_ERR_UNSORTED, EPI_ERR_NOMEM, EPI_ERR_NODEVICE, EPI_ERR_STATE = range(7)
 
@@ -102,6 +102,7 @@ _SIGS = {
     "epi_batch_mhl_fetch_dev": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), _VP]),
     "epi_batch_mhl_fetch_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), _VP]),
     "epi_tile_positions": (C.c_int, []),
+    "epi_cx_tile_positions": (C.c_int, [_CS]),
     "epi_batch_tile_key_range": (C.c_int, [_VP, _VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "epi_batch_cx_set_shared": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     "epi_batch_cx_finish_shared": (C.c_int, [_VP, _CS, _VP, C.POINTER(_I64)]),

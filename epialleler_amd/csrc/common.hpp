@@ -24,7 +24,10 @@ int fail(int code, const char *fmt, ...);
 #define EPI_TRY(expr) do { int _rc = (expr); if (_rc != EPI_OK) return _rc; } while (0)
 
 // ---- geometry ---------------------------------------------------------------
-constexpr int kTile = 1024;            // positions per CX tile (absolute grid)
+#ifndef EPI_CX_TILE
+#define EPI_CX_TILE 1024
+#endif
+constexpr int kTile = EPI_CX_TILE;     // positions per CX tile (absolute grid)
 constexpr int kMhlTile = 512;          // positions per lMHL tile (56 B of LDS counters per position and strand)
 constexpr int kCxPlanes = 16;          // [strand 2][counter 8] u32 planes of kTile entries
 constexpr int64_t kPosBias = 1LL << 31;// makes (start + bias) non-negative for any int32 start; multiple of every tile size
@@ -49,6 +52,15 @@ struct DevBuf {
 };
 
 struct ProfEntry { double ms = 0; int64_t n = 0; };
+
+// ---- per-read class counting shared by the per-read kernels and the fused CX tile kernel (per_read.hip) ----------
+struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // one byte per code: codes 0-3, 4-7, 8-11, 12-15
+struct ThrParams {                                   // rcpp_threshold_reads.cpp:15-23
+  uint32_t min_n_ctx;
+  double min_ctx_meth_frac, max_ooctx_meth_frac;
+};
+// 2-bit membership fields of up to four class strings in one LUT; false when a class string repeats a letter
+bool make_field_lut(const char *const cls[4], ClassLut *out);
 
 }  // namespace epi
 
@@ -100,12 +112,16 @@ struct epi_batch {
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes
   uint32_t cx_last_ctx_of_plane = 0;
   epi::DevBuf pass_tmp;                        // pass flags when thresholding could not be fused and the caller wants none
+  epi::DevBuf thr_tab;                         // fused thresholding: decision table for thr_tab_prm over totals 0..thr_tab_len
+  int32_t thr_tab_len = -1;
+  epi::ThrParams thr_tab_prm = {0, 0.0, 0.0};
   size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)
 
   // state of the last report (for fetch)
   int last_kind = 0;        // 0 none, 1 cx, 2 mhl
   int64_t last_nrow = 0;
   int32_t last_ntiles = 0;
+  int32_t last_tile = 0;    // tile size of the last CX report
 
   // multi-GPU shared tiles
   std::vector<int64_t> shared_keys;
@@ -169,13 +185,5 @@ inline int check_grid(int64_t blocks, int threads, const char *what) {
   return EPI_OK;
 }
 
-// ---- per-read class counting shared by the per-read kernels and the fused CX tile kernel (per_read.hip) ----------
-struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // one byte per code: codes 0-3, 4-7, 8-11, 12-15
-struct ThrParams {                                   // rcpp_threshold_reads.cpp:15-23
-  uint32_t min_n_ctx;
-  double min_ctx_meth_frac, max_ooctx_meth_frac;
-};
-// 2-bit membership fields of up to four class strings in one LUT; false when a class string repeats a letter
-bool make_field_lut(const char *const cls[4], ClassLut *out);
 
 }  // namespace epi

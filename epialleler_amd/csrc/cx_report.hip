@@ -7,23 +7,28 @@
 // '-') order.  A row (pos, strand, k) is emitted iff context k is reported and n_k = M_k + m_k > cov/2 (integer half,
 // strict): the counters of one position are disjoint and sum to at most cov, so n_k > cov/2 already excludes '.', and
 // every other context, from winning (:64-71).  Per (pos,strand) the table therefore needs only
-//   * (M, m) of each REPORTED context (one for a CG report, three for CX), and
+//   * (n, M) of each REPORTED context (one for a CG report, three for CX): calls of the context in either case, and
+//     the methylated ones of reads that passed (a failed read is lower-cased, :118,122); unmeth = n - M, and
 //   * cov = bases of rows covering the position, minus skipped codes ('+'/'-'/filler, :123), plus nibble 9 once more
 //     (it IS the reference's coverage slot, :126-127).
 //
-// A workgroup owns one tile of T positions on an absolute grid (tiles.hip); its candidate rows are a contiguous range.
-//  * Loads are POSITION-aligned: lane `sub` of the G lanes of a row loads the dwords that cover tile positions
-//    4k..4k+3 (unaligned global_load_dword; the hardware allows it), so the four bases of a dword land in ONE LDS cell.
-//  * Counters are u8, four positions per dword, (M | m) of a context side by side in one u64: ONE ds_add_u64 per
+// A workgroup owns one tile of T positions on an absolute grid (tiles.hip; T = 2048 for single-context reports,
+// 1024 otherwise); its candidate rows are a contiguous range.
+//  * Loads are POSITION-aligned: lane `sub` of the G lanes of a row loads 16-byte chunks that cover tile positions
+//    16c..16c+15 (global_load_dwordx4 at any byte alignment; the hardware allows it), so the four bases of a dword
+//    land in ONE LDS cell.
+//  * Counters are u8, four positions per dword, (n | M) of a context side by side in one u64: ONE ds_add_u64 per
 //    dword of xm and reported context (issued only by lanes whose dword holds a call) instead of one LDS atomic per
-//    base.  u8 counters are folded into u16 pairs every 192 rows (a row adds at most 1 per position and counter).
+//    base.  u8 counters are folded into u16 pairs every 255 rows (a row adds at most 1 per position and counter).
 //  * Coverage is a difference array (+1 at the first, -1 behind the last position of a row: two LDS atomics per row,
 //    both strands packed into one dword); skipped / doubled codes go to a second u8 array that is folded into it.
-//  * Fused thresholding (WHOLE = true): the G lanes load the WHOLE row (reads of up to 2.5 kb), count the four
-//    thresholding classes from the same registers (one v_perm LUT lookup per dword, 2-bit fields, DPP group sums),
-//    decide pass/fail as the reference does (IEEE divisions, :43-70) and then add the row's calls -- lower-cased when
-//    it failed (:118,122).  Rows that reach into two tiles are decided twice (same result); the xm bytes come from
-//    HBM once (the second visit is an L2 hit thanks to the XCD-aware tile order).
+//  * Fused thresholding (FUSED = true; the default generateCytosineReport call: report.context == threshold.context,
+//    one context): the G lanes load the WHOLE row (reads of up to ~5 kb), ONE v_perm LUT lookup per dword yields the
+//    four thresholding classes (2-bit fields: in context, methylated, out-of-context methylated / unmethylated) and
+//    the skip / double flags; field-wise adds, v_sad_u8 and DPP group sums give the read's totals, a table filled with
+//    the reference's own IEEE divisions (:43-70) turns them into pass / fail, and the same LUT bytes then give the
+//    calls.  Rows that reach into two tiles are decided twice (same result); the xm bytes come from HBM once (the
+//    second visit is an L2 hit thanks to the XCD-aware tile order).
 // After a barrier the workgroup prefix-sums the coverage array, lists the cells with any call (ballot ranks), applies
 // the rule and writes (key, meth, unmeth) in position order into the tile's slot of the row pool; k_cx_gather places
 // the pool rows in the final table.  Ultra-deep tiles are split over many workgroups through a slab in HBM; tiles
@@ -37,20 +42,31 @@
 namespace epi {
 
 constexpr int CX_WG = 512;                    // threads per tile workgroup (8 wavefronts)
-constexpr int CX2_NU = 10;                    // dwords a lane keeps in flight per row
-constexpr int CX_FLUSH_ROWS = 192;            // u8 -> u16 fold interval (multiple of the rows per round for every G)
-constexpr int CX_SLAB_COV = 12;               // slab planes [16][T]: 2*(strand*NP + p) + {0: M, 1: m}; 12, 13: coverage
+constexpr int CX_CH = 16;                     // bytes (= positions) of one position-aligned load
+constexpr int CX_FLUSH_ROWS = 255;            // u8 -> u16 fold interval: a row adds at most 1 per position and counter
+constexpr int CX_SLAB_COV = 12;               // slab planes [16][T]: 2*(strand*NP + p) + {0: n, 1: M}; 12, 13: coverage
                                               // difference array of '+', '-'; 14, 15 unused
 
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any alignment: global_load_dwordx4
+
+// Timing builds only (`make timing ABLATE=n` -> libepihip_t<n>.so, wrong results by design; the product library is
+// always built with 0): 1 aligned instead of position-aligned loads, 2 no call atomics, 4 no thresholding phase,
+// 8 loads only, 16 no emit, 32 no coverage atomics
+#ifndef EPI_CX_ABLATE
+#define EPI_CX_ABLATE 0
+#endif
 
 struct Cx2Args {
   RowCols c;                              // c.pass: external pass vector or null (all TRUE); ignored when fused
   int64_t xm_cap;                         // readable bytes behind c.xm
   const Tile *tiles;
-  ClassLut lut_r;                         // report LUT: byte = [M0 m0 M1 m1 M2 m2 skip dbl] one-hot flags of a code
-  ClassLut lut_t;                         // fused thresholding: 2-bit class fields (make_field_lut)
+  ClassLut lut_r;                         // report LUT: byte = [n0 M0 n1 M1 n2 M2 skip dbl] flags of a code (n: a call of
+                                          // plane p's context in either case, M: a methylated one)
+  ClassLut lut_s;                         // fused: bits 0,2,4,6 = in context / methylated / out-of-context methylated /
+                                          // unmethylated; 1,3 = skipped / doubled as is; 5,7 = the same when lower-cased
   ThrParams thr;
+  const uint32_t *thr_tab;                // fused thresholding without divisions: [n] = least passing n_m for n_m + n_u = n
+                                          // (low half), largest passing o_m for o_m + o_u = n (high half); k_thr_table
   uint32_t fill4;                         // 4 x a code without any flag in either LUT (stands in for bytes outside a row)
   uint32_t ctx_of_plane;                  // byte p = context code (2, 6, 7) of plane p
   int32_t *pass_out;                      // fused: pass flag of every row (may be null)
@@ -71,11 +87,11 @@ struct Cx2Args {
 
 template <int T, int NP> struct Cx2Lds {
   static constexpr int Q = T / 4;
-  static constexpr int N_NARROW = 2 * NP * Q;    // u64: [strand][plane][Q], low dword = M of 4 positions (u8), high = m
+  static constexpr int N_NARROW = 2 * NP * Q;    // u64: [strand][plane][Q], low dword = n of 4 positions (u8), high = M
   static constexpr int N_CORR = 2 * Q;           // u64: [strand][Q], low dword = skipped, high = doubled (u8 x 4)
-  static constexpr int N_WIDE = 2 * NP * T;      // u32: [strand][plane][T] = M | m << 16
-  static constexpr int N_COV = T + 4;            // u32: coverage difference array, '+' in the low half, '-' in the high half;
-                                                 // entry T = "behind the tile"
+  static constexpr int N_WIDE = 2 * NP * T;      // u32: [strand][plane][T] = n | M << 16
+  static constexpr int N_COV = T;                // u32: coverage difference array, '+' in the low half, '-' in the high half
+                                                 // (a change "behind the tile" is simply not recorded)
   unsigned long long *narrow, *corr;
   uint32_t *wide, *cov;
 };
@@ -92,7 +108,7 @@ template <int G>
 __device__ __forceinline__ uint32_t cx2_group_sum(uint32_t v) {     // over the G lanes of a row, every lane gets it
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);                  // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);                 // row_half_mirror
+  if (G >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror
   if (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);    // row_mirror
   if (G >= 32) v += __shfl_xor(v, 16, 64);
   if (G >= 64) v += __shfl_xor(v, 32, 64);
@@ -119,91 +135,228 @@ __device__ __forceinline__ int cx2_threshold(uint32_t n_m, uint32_t n_u, uint32_
   return res;
 }
 
-// One visit of up to G * CX2_NU position-aligned dwords of a row, starting at dword ks: loads (all in flight before
-// the first is used), then -- WHOLE -- the thresholding decision, then the calls.  `fetch_next` runs between the
-// loads and their first use (the caller fetches the next row's columns there).
+// The same decision from a table that k_thr_table fills by evaluating exactly the expressions above (IEEE
+// divisions, once per possible n instead of twice per read and tile visit): both comparisons are monotone in the
+// numerator, so per denominator n there is a least passing n_m and a largest passing o_m.
+__device__ __forceinline__ int cx2_threshold_tab(uint32_t n_m, uint32_t n_u, uint32_t o_m, uint32_t o_u, const ThrParams &prm,
+                                                 const uint32_t *__restrict__ tab) {
+  const uint32_t n_all = n_m + n_u, o_all = o_m + o_u;
+  const uint32_t least = tab[n_all] & 0xFFFFu, most = tab[o_all] >> 16;
+  return n_m != 0u && !(n_all < prm.min_n_ctx) && n_m >= least && (o_m == 0u || o_m <= most);
+}
+
+__global__ __launch_bounds__(256) void k_thr_table(ThrParams prm, int32_t nmax, uint32_t *__restrict__ tab) {
+  const int32_t n = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (n > nmax) return;
+  // least m in [1, n] with !((double)m / n < min_frac) (0xFFFF: none); the predicate is false..false true..true
+  uint32_t least = 0xFFFFu, most = 0u;
+  if (n >= 1) {
+    int32_t lo = 1, hi = n + 1;                              // first true in [lo, hi)
+    while (lo < hi) {
+      const int32_t m = (lo + hi) >> 1;
+      const double frac = (double)(uint32_t)m / (double)(uint32_t)n;
+      if (!(frac < prm.min_ctx_meth_frac)) hi = m; else lo = m + 1;
+    }
+    if (lo <= n) least = (uint32_t)lo;
+    // largest m in [1, n] with !((double)m / n > max_oo) (0: none); true..true false..false
+    lo = 1; hi = n + 1;                                      // first false in [lo, hi)
+    while (lo < hi) {
+      const int32_t m = (lo + hi) >> 1;
+      const double frac = (double)(uint32_t)m / (double)(uint32_t)n;
+      if (frac > prm.max_ooctx_meth_frac) hi = m; else lo = m + 1;
+    }
+    most = (uint32_t)(lo - 1);
+  }
+  tab[n] = least | (most << 16);
+}
+
+// bytes [lo,hi) of a dword set to 0xFF (any sign)
+__device__ __forceinline__ uint32_t cx2_byte_range(int lo, int hi) {
+  const int l = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+  const int h = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+  if (h <= l) return 0u;
+  const uint32_t mh = h == 4 ? ~0u : (1u << (8 * h)) - 1u;
+  const uint32_t ml = (1u << (8 * l)) - 1u;                 // l < 4 here
+  return mh & ~ml;
+}
+
+// One visit of up to G * NU position-aligned 16-byte chunks of a row, starting at chunk cs: loads (all in flight
+// before the first is used), then -- FUSED -- the thresholding decision, then the calls.  `fetch_next` runs between
+// the loads and their first use (the caller fetches the next row's columns there).
 struct Cx2Row {
   const uint8_t *base;                    // address of tile position 0 in the row's byte string (may lie outside the row)
-  int32_t rel, k0, klast;                 // tile position of byte 0; first / last position-aligned dword of the row
-  uint32_t mask_first, mask_last;         // bytes of those dwords that belong to the row
-  int back, fwd;                          // bytes the first / last dword would reach outside the buffer (edge rows only)
+  int32_t rel, len;                       // tile position of byte 0 (-Lmax < rel < T); bytes
+  int32_t c0, clast;                      // first / last position-aligned chunk of the row (chunk c = positions 16c..16c+15)
+  bool edge;                              // a chunk of the row reaches outside the buffer (first / last rows of a batch only)
   int sidx, ps;
 };
 
-template <int T, int G, int NP, bool WHOLE, class F>
-__device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t ks, int32_t kz, int sub, int rcur,
-                                          const Cx2Lds<T, NP> &L, F fetch_next) {
-  constexpr int Q = T / 4;
-  const int32_t kb = ks + sub;                                      // this lane's dwords: kb + u*G
-  const int32_t tl = kz - kb;                                       // dword u is part of the visit iff u*G <= tl
-  uint32_t w[CX2_NU];
-  if (__builtin_expect((g.back | g.fwd) != 0, 0)) {
+// byte masks of the four dwords of a chunk whose bytes [lo, 16) (FIRST) or [0, hi) belong to the row
+__device__ __forceinline__ void cx2_chunk_masks(int lo, int hi, uint32_t (&m)[4]) {
 #pragma unroll
-    for (int u = 0; u < CX2_NU; u++) {
-      const int32_t k = kb + u * G;
-      uint32_t x = a.fill4;
-      if (u * G <= tl) {
-        const int fb = k == g.k0 ? g.back : 0, ff = k == g.klast ? g.fwd : 0;
-        x = *reinterpret_cast<const u32_unaligned *>(g.base + 4 * (int64_t)k + fb - ff);
-        x = (x << (8 * fb)) >> (8 * ff);
+  for (int d = 0; d < 4; d++) m[d] = cx2_byte_range(lo - 4 * d, hi - 4 * d);
+}
+
+template <int T, int G, int NU, int NP, bool FUSED, class F>
+__device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t cs, int32_t cz, int sub, int rcur,
+                                          const Cx2Lds<T, NP> &L, F fetch_next) {
+  constexpr int C = T / CX_CH, Q = T / 4;
+  const int32_t cb = cs + sub;                                      // this lane's chunks: cb + u*G
+  const int32_t tl = cz - cb;                                       // chunk u is part of the visit iff u*G <= tl
+  uint32_t w[NU][4];
+  if (__builtin_expect(g.edge, 0)) {
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint32_t x = a.fill4;
+        if (u * G <= tl) {
+          const int64_t ad = (g.base - a.c.xm) + CX_CH * (int64_t)(cb + u * G) + 4 * d;
+          x = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int64_t q = ad + j;
+            const uint32_t byte = (q >= 0 && q < a.xm_cap) ? (uint32_t)a.c.xm[q] : (a.fill4 & 255u);
+            x |= byte << (8 * j);
+          }
+        }
+        w[u][d] = x;
       }
-      w[u] = x;
     }
   } else {
-    const uint8_t *p = g.base + 4 * (int64_t)kb;
+    const uint8_t *p = g.base + CX_CH * (int64_t)cb;
+    if (EPI_CX_ABLATE & 1) p = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
 #pragma unroll
-    for (int u = 0; u < CX2_NU; u++)
-      w[u] = u * G <= tl ? *reinterpret_cast<const u32_unaligned *>(p + 4 * u * G) : a.fill4;
+    for (int u = 0; u < NU; u++) {
+      if (u * G <= tl) {
+        const U4u v = *reinterpret_cast<const U4u *>(p + CX_CH * u * G);
+        w[u][0] = v.x; w[u][1] = v.y; w[u][2] = v.z; w[u][3] = v.w;
+      } else {
+        w[u][0] = w[u][1] = w[u][2] = w[u][3] = a.fill4;
+      }
+    }
   }
   fetch_next();
-  // bytes of the first / last dword that belong to neighbouring rows -> a code without flags
-  if (kb == g.k0) w[0] = (w[0] & g.mask_first) | (a.fill4 & ~g.mask_first);
+  if (EPI_CX_ABLATE & 8) {
+    uint32_t x = 0;
 #pragma unroll
-  for (int u = 0; u < CX2_NU; u++)
-    if (kb + u * G == g.klast) w[u] = (w[u] & g.mask_last) | (a.fill4 & ~g.mask_last);
-
-  if constexpr (WHOLE) {
-    // thresholding classes of the whole row: 2-bit fields, three dwords add field-wise (<= 3), split into even /
-    // odd 4-bit fields (<= 10 over a lane's 10 dwords), summed by v_sad_u8, two counts per word over the group
-    uint32_t E = 0, O = 0;
+    for (int u = 0; u < NU; u++) x ^= w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3];
+    if (x == 0x12345678u) atomicAdd(L.cov, 1u);
+    return;
+  }
+  // Bytes of the row's first / last chunk that belong to neighbouring rows -> a code without flags.  The first chunk
+  // is the first lane's first one; the last one can be any: its four masks are selected per chunk.
+  {
+    uint32_t mf[4], ml[4];
+    cx2_chunk_masks(cb == g.c0 ? (g.rel & 15) : 0, CX_CH, mf);
+    cx2_chunk_masks(0, ((g.rel + g.len - 1) & 15) + 1, ml);
 #pragma unroll
-    for (int u0 = 0; u0 < CX2_NU; u0 += 3) {
-      uint32_t t = 0;
+    for (int d = 0; d < 4; d++) w[0][d] = (w[0][d] & mf[d]) | (a.fill4 & ~mf[d]);
 #pragma unroll
-      for (int u = u0; u < u0 + 3 && u < CX2_NU; u++) t += cx2_lut(w[u], a.lut_t, 0x03020100u);
-      E += t & 0x33333333u;
-      O += (t >> 2) & 0x33333333u;
+    for (int u = 0; u < NU; u++) {
+      const bool last = cb + u * G == g.clast;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t m = last ? ml[d] : 0xFFFFFFFFu;
+        w[u][d] = (w[u][d] & m) | (a.fill4 & ~m);
+      }
     }
-    const uint32_t c0 = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, 0u), c2 = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, 0u);
-    const uint32_t c1 = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, 0u), c3 = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, 0u);
-    const uint32_t s01 = cx2_group_sum<G>(c0 | (c1 << 16)), s23 = cx2_group_sum<G>(c2 | (c3 << 16));
-    g.ps = cx2_threshold(s01 & 0xFFFFu, s01 >> 16, s23 & 0xFFFFu, s23 >> 16, a.thr);
-    if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;   // by the tile the row starts in
   }
 
-  // calls of the reported contexts: one ds_add_u64 per dword and plane, only from lanes that hold a call
-  const uint32_t pick0 = g.ps == 0 ? 0x07060504u : 0x03020100u;     // failed the threshold: lower-cased (:118)
-  unsigned long long *nar = L.narrow + g.sidx * NP * Q + kb;
-  unsigned long long *cor = L.corr + g.sidx * Q + kb;
+  unsigned long long *nar = L.narrow + g.sidx * NP * Q + 4 * cb;
+  unsigned long long *cor = L.corr + g.sidx * Q + 4 * cb;
+  if constexpr (FUSED) {
+    static_assert(NP == 1, "fused thresholding: one reported context, the thresholding context");
+    // One LUT lookup per dword, kept in place of the bytes.  Class totals of the whole row: 2-bit fields, three dwords
+    // add field-wise (<= 3), split into even / odd 4-bit fields (<= 12 over three chunks), summed by v_sad_u8, two
+    // counts per word over the group.
+    uint32_t E = 0, O = 0, cls[4] = {0, 0, 0, 0}, fl = 0;
 #pragma unroll
-  for (int u = 0; u < CX2_NU; u++) {
-    const uint32_t f = cx2_lut(w[u], a.lut_r, pick0);
-    const bool inside = (uint32_t)(kb + u * G) < (uint32_t)Q;        // (slice mode: always)
+    for (int u = 0; u < NU; u++) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-      const uint32_t lo = (f >> (2 * p)) & 0x01010101u, hi = (f >> (2 * p + 1)) & 0x01010101u;
-      if ((lo | hi) != 0u && inside) atomicAdd(nar + p * Q + u * G, (unsigned long long)lo | ((unsigned long long)hi << 32));
+      for (int d = 0; d < 4; d++) w[u][d] = (EPI_CX_ABLATE & 4) ? w[u][d] : cx2_lut(w[u][d], a.lut_s, 0x03020100u);
+      const uint32_t t = (w[u][0] & 0x55555555u) + (w[u][1] & 0x55555555u) + (w[u][2] & 0x55555555u);
+      const uint32_t d3 = w[u][3] & 0x55555555u;
+      E += (t & 0x33333333u) + (d3 & 0x33333333u);
+      O += ((t >> 2) & 0x33333333u) + ((d3 >> 2) & 0x33333333u);
+      fl |= w[u][0] | w[u][1] | w[u][2] | w[u][3];
+      if (u % 3 == 2 || u == NU - 1) {
+        cls[0] = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, cls[0]);         // in context (either case)
+        cls[2] = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, cls[2]);  // out of context, methylated
+        cls[1] = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, cls[1]);         // in context, methylated
+        cls[3] = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, cls[3]);  // out of context, unmethylated
+        E = 0; O = 0;
+      }
     }
-    if ((f & 0xC0C0C0C0u) != 0u && inside)
-      atomicAdd(cor + u * G, (unsigned long long)((f >> 6) & 0x01010101u) | ((unsigned long long)((f >> 7) & 0x01010101u) << 32));
+    const uint32_t s01 = cx2_group_sum<G>(cls[0] | (cls[1] << 16)), s23 = cx2_group_sum<G>(cls[2] | (cls[3] << 16));
+    const uint32_t n_all = s01 & 0xFFFFu, n_m = s01 >> 16;
+    g.ps = a.thr_tab ? cx2_threshold_tab(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr, a.thr_tab)
+                     : cx2_threshold(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr);
+    if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;   // by the tile the row starts in
+    // calls: n = in-context bytes, M = methylated ones of a passing read (a failed read is lower-cased, :118)
+    const uint32_t pm = g.ps ? 0x01010101u : 0u;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t lo = w[u][d] & 0x01010101u, hi = (w[u][d] >> 2) & pm;
+        if (lo != 0u && inside && !(EPI_CX_ABLATE & 2)) atomicAdd(nar + 4 * u * G + d, (unsigned long long)lo | ((unsigned long long)hi << 32));
+      }
+    }
+    // skipped / doubled codes (rare in WGS reads, common where mates do not meet): flags 1,3 as is, 5,7 lower-cased
+    const uint32_t fsel = g.ps ? 0x0A0A0A0Au : 0xA0A0A0A0u;
+    if (__builtin_expect((fl & fsel) != 0u, 0)) {
+      const int sh = g.ps ? 1 : 5;
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t sk = (w[u][d] >> sh) & 0x01010101u, db = (w[u][d] >> (sh + 2)) & 0x01010101u;
+          if ((sk | db) != 0u && inside) atomicAdd(cor + 4 * u * G + d, (unsigned long long)sk | ((unsigned long long)db << 32));
+        }
+      }
+    }
+  } else {
+    // calls of the reported contexts: one ds_add_u64 per dword and plane, only from lanes that hold a call
+    const uint32_t pick0 = g.ps == 0 ? 0x07060504u : 0x03020100u;   // failed the threshold: lower-cased (:118)
+    uint32_t fl = 0;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;      // (always: the visit stays inside the tile)
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t f = cx2_lut(w[u][d], a.lut_r, pick0);
+        w[u][d] = f;
+        fl |= f;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const uint32_t lo = (f >> (2 * p)) & 0x01010101u, hi = (f >> (2 * p + 1)) & 0x01010101u;
+          if (lo != 0u && inside && !(EPI_CX_ABLATE & 2))
+            atomicAdd(nar + p * Q + 4 * u * G + d, (unsigned long long)lo | ((unsigned long long)hi << 32));
+        }
+      }
+    }
+    if (__builtin_expect((fl & 0xC0C0C0C0u) != 0u, 0)) {
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t sk = (w[u][d] >> 6) & 0x01010101u, db = (w[u][d] >> 7) & 0x01010101u;
+          if ((sk | db) != 0u && inside) atomicAdd(cor + 4 * u * G + d, (unsigned long long)sk | ((unsigned long long)db << 32));
+        }
+      }
+    }
   }
 }
 
 // Rows [row_lo, row_hi) of the tile into the u8 counters and the coverage array.  G lanes own a row (64/G rows per
 // wavefront step); the next step's row columns are fetched while the current row's bytes are in flight.
-template <int T, int G, int NP, bool WHOLE>
+template <int T, int G, int NU, int NP, bool FUSED>
 __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
-  constexpr int R = 64 / G, NW = CX_WG / 64, Q = T / 4;
+  constexpr int R = 64 / G, NW = CX_WG / 64, C = T / CX_CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   Tile tb = td;
@@ -217,31 +370,26 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
     bool fetched = false;
     auto fetch_next = [&]() { if (!fetched) { nv = cx_load_row(a.c, tb, r); fetched = true; } };
     if (v.ok && v.len > 0) {
-      // geometry: rel = tile position of the row's byte 0 (-Lmax < rel < T); the row's bytes sit in the
-      // position-aligned dwords k0..klast (dword k = tile positions 4k..4k+3)
       Cx2Row g;
       g.rel = (int32_t)((uint32_t)v.st - (uint32_t)td.pos0);
-      g.k0 = g.rel >> 2;
-      g.klast = (g.rel + v.len - 1) >> 2;
+      g.len = v.len;
+      g.c0 = g.rel >> 4;
+      g.clast = (g.rel + v.len - 1) >> 4;
       g.base = a.c.xm + (v.o - g.rel);
-      g.mask_first = 0xFFFFFFFFu << (8 * (g.rel & 3));
-      g.mask_last = 0xFFFFFFFFu >> (8 * (3 - ((g.rel + v.len - 1) & 3)));
-      // the first / last dword may start before / end behind the buffer (first and last rows of a batch only)
-      const int64_t a0 = v.o - (g.rel & 3), a1 = v.o - g.rel + 4 * (int64_t)g.klast + 4;
-      g.back = a0 < 0 ? (int)-a0 : 0;
-      g.fwd = a1 > a.xm_cap ? (int)(a1 - a.xm_cap) : 0;
+      // the first / last chunk may start before / end behind the buffer (first and last rows of a batch only)
+      g.edge = v.o < CX_CH || v.o + v.len + CX_CH > a.xm_cap;
       g.sidx = v.sd - 1;
       g.ps = v.ps;
-      if constexpr (WHOLE) {
-        cx2_visit<T, G, NP, true>(a, g, g.k0, g.klast, sub, rcur, L, fetch_next);     // the host made sure the row fits
+      if constexpr (FUSED) {
+        cx2_visit<T, G, NU, NP, true>(a, g, g.c0, g.clast, sub, rcur, L, fetch_next);     // the host made sure the row fits
       } else {
-        const int32_t ka = g.k0 > 0 ? g.k0 : 0, kz = g.klast < Q - 1 ? g.klast : Q - 1;   // the slice inside the tile
-        for (int32_t ks = ka; ks <= kz; ks += G * CX2_NU) cx2_visit<T, G, NP, false>(a, g, ks, kz, sub, rcur, L, fetch_next);
+        const int32_t ca = g.c0 > 0 ? g.c0 : 0, cz = g.clast < C - 1 ? g.clast : C - 1;   // the slice inside the tile
+        for (int32_t cs = ca; cs <= cz; cs += G * NU) cx2_visit<T, G, NU, NP, false>(a, g, cs, cz, sub, rcur, L, fetch_next);
       }
       if (sub == 0) {                                                 // coverage: +1 on the row's positions inside the tile
         const int32_t ca = g.rel > 0 ? g.rel : 0, cb = g.rel + v.len < T ? g.rel + v.len : T;
         const uint32_t unit = g.sidx ? 65536u : 1u;
-        if (ca < cb) { atomicAdd(L.cov + ca, unit); atomicAdd(L.cov + cb, 0u - unit); }
+        if (ca < cb && !(EPI_CX_ABLATE & 32)) { atomicAdd(L.cov + ca, unit); if (cb < T) atomicAdd(L.cov + cb, 0u - unit); }
       }
     }
     fetch_next();
@@ -281,7 +429,7 @@ __device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP> &L) {
       if (d != prev) atomicAdd(L.cov + 4 * q + j, (uint32_t)((d - prev) * unit));
       prev = d;
     }
-    if (prev != 0) atomicAdd(L.cov + 4 * q + 4, (uint32_t)(-prev * unit));
+    if (prev != 0 && 4 * q + 4 < T) atomicAdd(L.cov + 4 * q + 4, (uint32_t)(-prev * unit));
   }
 }
 
@@ -304,9 +452,9 @@ template <int T, int NP> struct CxSrcLds {
     for (int p = 0; p < NP; p++) x |= wide[(sd * NP + p) * T + pos];
     return x;
   }
-  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *M, uint32_t *m) const {
+  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *n, uint32_t *M) const {
     const uint32_t w = wide[(sd * NP + p) * T + pos];
-    *M = w & 0xFFFFu; *m = w >> 16;
+    *n = w & 0xFFFFu; *M = w >> 16;
   }
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
 };
@@ -317,11 +465,11 @@ template <int T, int NP> struct CxSrcSlab {
   __device__ __forceinline__ uint32_t any(int sd, int pos) const {
     uint32_t x = 0;
 #pragma unroll
-    for (int p = 0; p < NP; p++) x |= (uint32_t)slab[(2 * (sd * NP + p)) * T + pos] | (uint32_t)slab[(2 * (sd * NP + p) + 1) * T + pos];
+    for (int p = 0; p < NP; p++) x |= (uint32_t)slab[(2 * (sd * NP + p)) * T + pos];
     return x;
   }
-  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *M, uint32_t *m) const {
-    *M = (uint32_t)slab[(2 * (sd * NP + p)) * T + pos]; *m = (uint32_t)slab[(2 * (sd * NP + p) + 1) * T + pos];
+  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *n, uint32_t *M) const {
+    *n = (uint32_t)slab[(2 * (sd * NP + p)) * T + pos]; *M = (uint32_t)slab[(2 * (sd * NP + p) + 1) * T + pos];
   }
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { return cov[sd * T + pos]; }
 };
@@ -355,7 +503,7 @@ __device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
 template <int T, int NP, class SRC>
 __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &src, uint32_t *s_scan, uint16_t *s_list) {
   constexpr int NW = CX_WG / 64, PW = T / NW, IT = PW / 32;
-  static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");
+  static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");   // IT = 4 (T = 1024) or 8 (2048)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l5 = lane & 31, sd = lane >> 5;
   const uint32_t below = (1u << l5) - 1u;
@@ -387,9 +535,9 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
         uint32_t ctx = 0, m = 0, u = 0;
 #pragma unroll
         for (int p = 0; p < NP; p++) {                                     // :65-71 (at most one context can exceed half)
-          uint32_t M, mm;
-          src.pair(st, p, pos, &M, &mm);
-          if (M + mm > half && ctx == 0) { ctx = (a.ctx_of_plane >> (8 * p)) & 255u; m = M; u = mm; }
+          uint32_t nn, M;
+          src.pair(st, p, pos, &nn, &M);
+          if (nn > half && ctx == 0) { ctx = (a.ctx_of_plane >> (8 * p)) & 255u; m = M; u = nn - M; }
         }
         good = ctx != 0;
         key[jj] = ((uint32_t)pos << 4) | ((uint32_t)st << 3) | ctx;
@@ -465,11 +613,16 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
 
 // workgroups per CU by LDS (the u8 arrays double as the emit phase's candidate lists) and the 2048-thread limit
 template <int T, int NP> constexpr int cx2_lds_bytes() {
-  return (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 + (Cx2Lds<T, NP>::N_WIDE + Cx2Lds<T, NP>::N_COV) * 4 + 64;
+  return (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 + (Cx2Lds<T, NP>::N_WIDE + Cx2Lds<T, NP>::N_COV) * 4;
 }
-template <int T, int NP> constexpr int cx2_waves_per_simd() {
+#ifndef EPI_CX_WPS
+#define EPI_CX_WPS 8
+#endif
+template <int T, int NP, int NU = 3> constexpr int cx2_waves_per_simd() {
   const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP>(), by_thr = 2048 / CX_WG;
-  const int wgs = by_lds < by_thr ? by_lds : by_thr;
+  int wgs = by_lds < by_thr ? by_lds : by_thr;
+  if (NU >= 4 && wgs > 3) wgs = 3;                        // four chunks per lane in flight need 80 VGPRs
+  if (wgs * CX_WG / 256 > EPI_CX_WPS) wgs = EPI_CX_WPS * 256 / CX_WG;
   return (wgs < 1 ? 1 : wgs) * CX_WG / 256;
 }
 
@@ -477,7 +630,9 @@ template <int T, int NP> constexpr int cx2_waves_per_simd() {
   __shared__ __attribute__((aligned(16))) unsigned long long s_u8[Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR]; \
   __shared__ __attribute__((aligned(16))) uint32_t s_wide[Cx2Lds<T, NP>::N_WIDE];                                \
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[Cx2Lds<T, NP>::N_COV];                                  \
-  static_assert((Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 >= 4 * T, "the candidate lists reuse the u8 arrays"); \
+  static_assert((Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 >= 4 * T + 64, "the candidate lists and the scan scratch reuse the u8 arrays"); \
+  uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_u8) + T;   /* (dead until the last fold is done) */             \
+  (void)s_scan;                                                                                                   \
   Cx2Lds<T, NP> L;                                                                                               \
   L.narrow = s_u8; L.corr = s_u8 + Cx2Lds<T, NP>::N_NARROW; L.wide = s_wide; L.cov = s_cov;
 
@@ -492,21 +647,20 @@ __device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP> &L) {
 }
 
 // rows [row_lo, row_hi) of a tile, folded every CX_FLUSH_ROWS rows; leaves everything in `wide` and `cov`
-template <int T, int G, int NP, bool WHOLE>
+template <int T, int G, int NU, int NP, bool FUSED>
 __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
   for (int b0 = row_lo; b0 < row_hi; b0 += CX_FLUSH_ROWS) {
     if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP>(L); __syncthreads(); }
-    cx2_rows<T, G, NP, WHOLE>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
+    cx2_rows<T, G, NU, NP, FUSED>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
   }
   __syncthreads();
   cx2_flush<T, NP>(L);
   __syncthreads();
 }
 
-template <int T, int G, int NP, bool WHOLE>
-__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+template <int T, int G, int NU, int NP, bool FUSED>
+__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_tiles(Cx2Args a, int ntiles) {
   CX2_SHARED(T, NP)
-  __shared__ uint32_t s_scan[CX_WG / 64 + 2];
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
@@ -523,13 +677,14 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_til
     return;
   }
   __syncthreads();
-  cx2_accumulate<T, G, NP, WHOLE>(a, td, td.row_lo, td.row_hi, L);
+  cx2_accumulate<T, G, NU, NP, FUSED>(a, td, td.row_lo, td.row_hi, L);
   if (td.slot >= 0) {
     // shared with another rank: hand the raw sums over
     cx2_dump_slab<T, NP>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
+  if (EPI_CX_ABLATE & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   cx2_prefix<T>(L.cov, s_scan);
   CxSrcLds<T, NP> src;
   src.wide = L.wide; src.cov = L.cov;
@@ -538,8 +693,8 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_til
 
 // One chunk of the candidate rows of one heavy tile: LDS sums as usual, then added into the tile's slab in HBM (or
 // straight into its shared slab slot when other ranks contribute too).
-template <int T, int G, int NP, bool WHOLE>
-__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_heavy(Cx2Args a) {
+template <int T, int G, int NU, int NP, bool FUSED>
+__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_heavy(Cx2Args a) {
   CX2_SHARED(T, NP)
   const int tile = (int)a.heavy_list[blockIdx.y];
   const Tile td = a.tiles[tile];
@@ -548,7 +703,7 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP>())) void k_cx_hea
   const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
   cx2_clear<T, NP>(L);
   __syncthreads();
-  cx2_accumulate<T, G, NP, WHOLE>(a, td, lo, hi, L);
+  cx2_accumulate<T, G, NU, NP, FUSED>(a, td, lo, hi, L);
   cx2_dump_slab<T, NP>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
                                         : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
 }
@@ -615,57 +770,68 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 
-// lanes per row: whole rows (fused thresholding) must fit one round of CX2_NU dwords per lane, slices should
-static int pick_cx_group(int32_t max_len, int T, bool whole) {
-  const int span = (whole ? max_len : (max_len < T ? max_len : T)) + 6;   // + misalignment at both ends
-  const int nd = (span + 3) / 4;
-  int g = 8;
-  while (g < 64 && g * CX2_NU < nd) g <<= 1;
-  return g;
+// Tile size: 2048 positions for a single reported context (40 KiB of LDS, four workgroups per CU, fewer rows that
+// reach into two tiles, fuller rounds), 1024 with two or three contexts (their counters take 32 / 44 KiB).
+static int cx_tile_for(int np) { return np <= 1 ? 2048 : 1024; }
+
+// Lanes per row and 16-byte chunks per lane.  Whole rows (fused thresholding) must fit one visit of G * NU chunks
+// wherever they start inside their first chunk; slices of longer rows loop.  Returned as G * 8 + NU.
+static int pick_cx_shape(int32_t max_len, int T, bool fused) {
+  const int64_t span = (fused ? (int64_t)max_len : (max_len < T ? max_len : T)) + (CX_CH - 1);
+  const int chunks = (int)((span + CX_CH - 1) / CX_CH);
+#ifdef EPI_CX_FORCE_SHAPE                                  // timing builds only: (G, NU) = (EPI_CX_FORCE_SHAPE / 8, % 8)
+  if (fused) return EPI_CX_FORCE_SHAPE;
+#endif
+  if (fused) {
+    for (int g = 4; g <= 64; g <<= 1) {
+      if (g * 3 >= chunks) return g * 8 + 3;
+      if (g * 5 >= chunks) return g * 8 + 5;
+    }
+    return 64 * 8 + 5;
+  }
+  for (int g = 8; g < 64; g <<= 1)
+    if (g * 3 >= chunks) return g * 8 + 3;
+  return 64 * 8 + 3;
 }
-static bool cx_whole_fits(int32_t max_len) { return ((int64_t)max_len + 6 + 3) / 4 <= 64 * CX2_NU; }
+static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 5; }
 
-int cx_tile_positions() { return kTile; }
-
-template <int T, int NP, bool WHOLE>
+template <int T, int NU, int NP, bool FUSED>
 static void launch_cx_g(bool heavy, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   if (!heavy) {
     const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
     switch (g) {
-      case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NP, WHOLE>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); } break;
+      case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+      default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
     }
     return;
   }
   switch (g) {
-    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, NP, WHOLE>), grid, dim3(CX_WG), 0, s, a); break;
+    case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_heavy<T, 4, NU, NP, FUSED>), grid, dim3(CX_WG), 0, s, a); } break;
+    case 8: hipLaunchKernelGGL((k_cx_heavy<T, 8, NU, NP, FUSED>), grid, dim3(CX_WG), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_cx_heavy<T, 16, NU, NP, FUSED>), grid, dim3(CX_WG), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_cx_heavy<T, 32, NU, NP, FUSED>), grid, dim3(CX_WG), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_cx_heavy<T, 64, NU, NP, FUSED>), grid, dim3(CX_WG), 0, s, a); break;
   }
   hipLaunchKernelGGL((k_cx_emit_heavy<T, NP>), dim3(grid.y), dim3(CX_WG), 0, s, a);
 }
 
-static void launch_cx(bool heavy, int np, bool whole, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
-  constexpr int T = kTile;
-  if (whole) {
-    if (np == 1) launch_cx_g<T, 1, true>(heavy, g, nt, grid, s, a);
-    else if (np == 2) launch_cx_g<T, 2, true>(heavy, g, nt, grid, s, a);
-    else launch_cx_g<T, 3, true>(heavy, g, nt, grid, s, a);
-  } else {
-    if (np == 1) launch_cx_g<T, 1, false>(heavy, g, nt, grid, s, a);
-    else if (np == 2) launch_cx_g<T, 2, false>(heavy, g, nt, grid, s, a);
-    else launch_cx_g<T, 3, false>(heavy, g, nt, grid, s, a);
-  }
+static void launch_cx(bool heavy, int np, bool fused, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+  const int g = shape >> 3, nu = shape & 7;
+  if (fused) {                                             // one context, 2048-position tiles
+    if (nu == 3) launch_cx_g<2048, 3, 1, true>(heavy, g, nt, grid, s, a);
+    else launch_cx_g<2048, 5, 1, true>(heavy, g, nt, grid, s, a);
+  } else if (np == 1) launch_cx_g<2048, 3, 1, false>(heavy, g, nt, grid, s, a);
+  else if (np == 2) launch_cx_g<1024, 3, 2, false>(heavy, g, nt, grid, s, a);
+  else launch_cx_g<1024, 3, 3, false>(heavy, g, nt, grid, s, a);
 }
 
 static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
-  constexpr int T = kTile;
-  if (np == 1) hipLaunchKernelGGL((k_cx_emit_slab<T, 1>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
-  else if (np == 2) hipLaunchKernelGGL((k_cx_emit_slab<T, 2>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
-  else hipLaunchKernelGGL((k_cx_emit_slab<T, 3>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  if (np == 1) hipLaunchKernelGGL((k_cx_emit_slab<2048, 1>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else if (np == 2) hipLaunchKernelGGL((k_cx_emit_slab<1024, 2>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  else hipLaunchKernelGGL((k_cx_emit_slab<1024, 3>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
 }
 
 static int ensure_pool(epi_batch *b, size_t rows) {
@@ -685,8 +851,8 @@ static int make_report_lut(uint32_t ctx_mask, ClassLut *lut, uint32_t *ctx_of_pl
   *ctx_of_plane = 0;
   for (uint32_t k : {2u, 6u, 7u}) {
     if (!((ctx_mask >> k) & 1u)) continue;
-    f[k] |= 1u << (2 * np);                                // methylated: M of plane np
-    f[k + 8] |= 1u << (2 * np + 1);                        // unmethylated (or lower-cased): m
+    f[k] |= 3u << (2 * np);                                // methylated: a call (n) and M of plane np
+    f[k + 8] |= 1u << (2 * np);                            // unmethylated (or lower-cased): a call only
     *ctx_of_plane |= k << (8 * np);
     np++;
   }
@@ -707,8 +873,44 @@ struct CxThreshold {                      // fused thresholding request (null = 
   ThrParams prm;
 };
 
+// The fused kernel's LUT.  Fusable: the report has one context k, the thresholding classes are that context
+// (ctx_meth = {k}, ctx_unmeth = {k | 8}) and no class string repeats a letter.  Also picks the stand-in code for bytes
+// outside a row (no bit set in this LUT).
+static bool make_fused_lut(const CxThreshold &t, uint32_t ctx_of_plane, int np, ClassLut *lut, uint32_t *fill4) {
+  if (np != 1) return false;
+  const uint32_t k = ctx_of_plane & 255u;
+  unsigned w[4][16] = {{0}};
+  for (int c = 0; c < 4; c++)
+    if (t.cls[c]) for (const unsigned char *p = reinterpret_cast<const unsigned char *>(t.cls[c]); *p; p++) w[c][ctx_to_idx(*p)]++;
+  for (int c = 0; c < 4; c++) for (int i = 0; i < 16; i++) if (w[c][i] > 1) return false;
+  for (uint32_t i = 0; i < 16; i++) {
+    if ((w[0][i] != 0) != (i == k)) return false;          // ctx_meth is exactly the reported context's methylated code
+    if ((w[1][i] != 0) != (i == (k | 8u))) return false;   // ctx_unmeth its unmethylated one
+  }
+  uint32_t f[16];
+  for (uint32_t i = 0; i < 16; i++) {
+    f[i] = 0;
+    if (i == k || i == (k | 8u)) f[i] |= 0x01u;            // in context, either case: n_m + n_u, and a call
+    if (i == k) f[i] |= 0x04u;                             // methylated: n_m, and M for a passing read
+    if (w[2][i]) f[i] |= 0x10u;
+    if (w[3][i]) f[i] |= 0x40u;
+    if (i == 11) f[i] |= 0x02u;                            // skipped as is (:123) ...
+    if (i == 9) f[i] |= 0x08u;                             // counts twice in the coverage (:126-127)
+    if ((i | 8u) == 11) f[i] |= 0x20u;                     // ... and when the read is lower-cased (c | 8, :122)
+    if ((i | 8u) == 9) f[i] |= 0x80u;
+  }
+  int fill = -1;
+  for (int c : {12, 8, 0, 4}) if (f[c] == 0) { fill = c; break; }
+  if (fill < 0) return false;
+  auto pack = [&](int b0) { return f[b0] | (f[b0 + 1] << 8) | (f[b0 + 2] << 16) | (f[b0 + 3] << 24); };
+  lut->lo0 = pack(0); lut->lo1 = pack(4); lut->hi0 = pack(8); lut->hi1 = pack(12);
+  *fill4 = 0x01010101u * (uint32_t)fill;
+  return true;
+}
+
 // The CX report on a resident batch.  thr != null: thresholding fused into the tile kernel when the batch allows it
-// (class strings without repeated letters, reads of at most ~2.5 kb), else a separate pass of the per-read kernel.
+// (the report's one context is the thresholding context, reads of at most ~5 kb), else a separate pass of the
+// per-read kernel first.
 static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold *thr, int32_t *d_pass_out, const char *ctx,
                           hipStream_t s, int64_t *nrow_out) {
   *nrow_out = 0;
@@ -716,43 +918,48 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   uint32_t ctx_mask = 0;                                   // rcpp_cx_report.cpp:88-91
   for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
 
-  constexpr int T = kTile;
+  Cx2Args a;
+  memset(&a, 0, sizeof(a));
+  const int np = make_report_lut(ctx_mask, &a.lut_r, &a.ctx_of_plane);
+  const int T = cx_tile_for(np);
   RowStats st;
   int32_t nt = 0;
   EPI_TRY(build_tiles(b, s, T, &st, &nt));
   b->last_ntiles = nt;
-
-  Cx2Args a;
-  memset(&a, 0, sizeof(a));
-  const int np = make_report_lut(ctx_mask, &a.lut_r, &a.ctx_of_plane);
+  b->last_tile = T;
   a.fill4 = 0x0C0C0C0Cu;                                   // '.': never a call, never skipped, also when lower-cased
-  bool whole = false;
-  DevBuf *own_pass = nullptr;
+  bool fused = false;
   if (thr) {
-    ClassLut ft;
-    int fill = -1;
-    if (make_field_lut(thr->cls, &ft) && cx_whole_fits(st.max_len)) {
-      for (int c : {12, 8, 0, 4})                          // a code outside every class whose report flags are empty either way
-        if (lut_byte(ft, c) == 0 && lut_byte(a.lut_r, c) == 0 && lut_byte(a.lut_r, c | 8) == 0) { fill = c; break; }
-    }
-    if (fill >= 0 && nt > 0 && np > 0) {
-      whole = true;
-      a.lut_t = ft;
+    uint32_t fill4 = 0;
+    if (nt > 0 && np > 0 && cx_fused_fits(st.max_len) && make_fused_lut(*thr, a.ctx_of_plane, np, &a.lut_s, &fill4)) {
+      fused = true;
       a.thr = thr->prm;
-      a.fill4 = 0x01010101u * (uint32_t)fill;
+      a.fill4 = fill4;
       a.pass_out = d_pass_out;
+      // decisions from a table over the possible class totals (filled on the device with the reference's own
+      // expressions); kept while the thresholds do not change
+      const bool same = b->thr_tab_len == st.max_len && memcmp(&b->thr_tab_prm, &thr->prm, sizeof(ThrParams)) == 0;
+      if (!same) {
+        EPI_TRY(b->thr_tab.ensure((size_t)(st.max_len + 1) * 4));
+        hipLaunchKernelGGL(k_thr_table, dim3((unsigned)(st.max_len / 256 + 1)), dim3(256), 0, s, thr->prm, st.max_len, b->thr_tab.as<uint32_t>());
+        EPI_HIP(hipGetLastError());
+        b->thr_tab_len = st.max_len;
+        memset(&b->thr_tab_prm, 0, sizeof(ThrParams));
+        b->thr_tab_prm.min_n_ctx = thr->prm.min_n_ctx;
+        b->thr_tab_prm.min_ctx_meth_frac = thr->prm.min_ctx_meth_frac;
+        b->thr_tab_prm.max_ooctx_meth_frac = thr->prm.max_ooctx_meth_frac;
+      }
+      a.thr_tab = b->thr_tab.as<uint32_t>();
     } else if (b->n > 0) {
       // not fusable: the per-read kernel decides first (into the caller's buffer, or a scratch column)
       int32_t *dst = d_pass_out;
-      if (!dst) { EPI_TRY(b->pass_tmp.ensure((size_t)b->n * 4)); dst = b->pass_tmp.as<int32_t>(); own_pass = &b->pass_tmp; }
+      if (!dst) { EPI_TRY(b->pass_tmp.ensure((size_t)b->n * 4)); dst = b->pass_tmp.as<int32_t>(); }
       EPI_TRY(epi_batch_threshold_reads_dev(b, thr->cls[0], thr->cls[1], thr->cls[2] ? thr->cls[2] : "", thr->cls[3] ? thr->cls[3] : "",
                                             thr->prm.min_n_ctx, thr->prm.min_ctx_meth_frac, thr->prm.max_ooctx_meth_frac, dst, s));
       d_pass = dst;
     }
   }
-  (void)own_pass;
   if (nt == 0 || np == 0) {                                // no rows, or a context string without H/X/Z: an empty table
-    if (nt > 0) { /* tiles exist but nothing is reported */ }
     b->last_kind = 1; b->last_nrow = 0; b->last_ntiles = 0;
     return EPI_OK;
   }
@@ -782,10 +989,10 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     slot = 0;                                              // the slots do not fit in device memory: every tile through the
     ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
-  const int grp = pick_cx_group(st.max_len, T, whole);
+  const int grp = pick_cx_shape(st.max_len, T, fused);   // lanes per row * 8 + chunks per lane
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
-  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = whole ? nullptr : d_pass;
+  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
   a.tiles = b->tiles.as<Tile>();
   a.cursor = cursor;
@@ -819,7 +1026,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     }
     prof_begin("cx_tiles", s);
-    launch_cx(false, np, whole, grp, nt, dim3(1), s, a);
+    launch_cx(false, np, fused, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
@@ -833,7 +1040,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
       prof_begin("cx_heavy", s);
-      launch_cx(true, np, whole, grp, nt, dim3(nchunks, nheavy), s, a);
+      launch_cx(true, np, fused, grp, nt, dim3(nchunks, nheavy), s, a);
       prof_end("cx_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -861,7 +1068,14 @@ using namespace epi;
 
 extern "C" {
 
-int epi_tile_positions(void) { return cx_tile_positions(); }
+int epi_tile_positions(void) { return cx_tile_for(1); }
+
+int epi_cx_tile_positions(const char *ctx) {
+  uint32_t ctx_mask = 0, cop = 0;
+  if (ctx) for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
+  ClassLut l;
+  return cx_tile_for(make_report_lut(ctx_mask, &l, &cop));
+}
 
 int epi_batch_cx_report_dev(epi_batch *b, const int32_t *d_pass, const char *ctx, void *stream, int64_t *nrow_out) {
   if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_dev: NULL argument");
@@ -951,7 +1165,7 @@ int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *
 }
 
 int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int64_t *last_key) {
-  return epi_batch_tile_key_range_for(b, cx_tile_positions(), stream, first_key, last_key);
+  return epi_batch_tile_key_range_for(b, cx_tile_for(1), stream, first_key, last_key);
 }
 
 int epi_batch_tile_key_range_for(epi_batch *b, int tile_positions, void *stream, int64_t *first_key, int64_t *last_key) {

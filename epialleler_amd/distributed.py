@@ -78,26 +78,27 @@ class HipShardEngine:
         self._range = {}
         self.last_exchange_bytes = 0          # bytes this rank handed to the last report's all-reduce(s)
 
-    def tile_positions(self):
-        return self.lib.epi_tile_positions()
+    def tile_positions(self, ctx="Z"):
+        """Positions per CX tile for this report context string (one reported context: 2048, else 1024)."""
+        return self.lib.epi_cx_tile_positions(_lib.enc(ctx))
 
-    def key_range(self, kind="cx"):
+    def key_range(self, kind="cx", ctx="Z"):
         # a property of the resident (immutable) shard and the tile grid: computed once per tile size
-        if kind not in self._range:
-            T = self.lib.epi_tile_positions() if kind == "cx" else self.lib.epi_mhl_tile_positions()
+        T = self.tile_positions(ctx) if kind == "cx" else self.lib.epi_mhl_tile_positions()
+        if (kind, T) not in self._range:
             a, b = C.c_int64(0), C.c_int64(-1)
             _lib.check(self.lib.epi_batch_tile_key_range_for(self.h, T, _stream(self.bam.device), C.byref(a), C.byref(b)))
-            self._range[kind] = (a.value, b.value)
-        return self._range[kind]
+            self._range[(kind, T)] = (a.value, b.value)
+        return self._range[(kind, T)]
 
     def threshold(self, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n, min_frac, max_oo):
         from .api import rcpp_threshold_reads
         return rcpp_threshold_reads(self.bam, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n, min_frac,
                                     max_oo, as_device=True)
 
-    def _attach_cx_slab(self, keys, owned):
+    def _attach_cx_slab(self, keys, owned, ctx):
         torch = self.torch
-        T = self.tile_positions()
+        T = self.tile_positions(ctx)
         want = max(keys.size, 1) * 16 * T
         if self._slab is None or self._slab.numel() != want:
             self._slab = torch.zeros(want, dtype=torch.int32, device=self.device)
@@ -113,7 +114,7 @@ class HipShardEngine:
         return self._slab
 
     def cx_accumulate(self, pass_, ctx, keys, owned):
-        self._attach_cx_slab(keys, owned)
+        self._attach_cx_slab(keys, owned, ctx)
         self._nshared = int(keys.size)
         nrow = C.c_int64(0)
         _lib.check(self.lib.epi_batch_cx_report_dev(
@@ -124,7 +125,7 @@ class HipShardEngine:
 
     def cx_accumulate_fused(self, thr, ctx, keys, owned):
         """cx_accumulate with the thresholding (thr = the seven rcpp_threshold_reads arguments) done inside the tile kernel."""
-        slab = self._attach_cx_slab(keys, owned)
+        slab = self._attach_cx_slab(keys, owned, ctx)
         nrow = C.c_int64(0)
         _lib.check(self.lib.epi_batch_cytosine_report_dev(
             self.h, _lib.enc(thr[0]), _lib.enc(thr[1]), _lib.enc(thr[2]), _lib.enc(thr[3]), int(thr[4]), float(thr[5]),
@@ -183,7 +184,7 @@ class HipShardEngine:
         return icols, dcols
 
 
-def _exchange_ranges(engine, kind, group):
+def _exchange_ranges(engine, kind, group, ctx="Z"):
     """all_gather of every rank's (first,last) tile key -> (ranges, world, rank).  The shards and the tile grid do not
     change, so the exchange is done once per (engine, tile grid, group) and remembered on the engine."""
     import torch
@@ -191,9 +192,11 @@ def _exchange_ranges(engine, kind, group):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     memo = engine.__dict__.setdefault("_all_ranges", {})
+    T = engine.tile_positions(ctx) if kind == "cx" else 0
+    kind = (kind, T)
     if (kind, id(group), world) in memo:
         return memo[(kind, id(group), world)], world, rank
-    first, last = engine.key_range(kind) if kind != "cx" else engine.key_range()
+    first, last = engine.key_range(kind[0]) if kind[0] != "cx" else engine.key_range("cx", ctx)
     if world > 1:
         mine = torch.tensor([first, last], dtype=torch.int64, device=engine.device)
         allr = [torch.empty(2, dtype=torch.int64, device=engine.device) for _ in range(world)]
@@ -270,7 +273,7 @@ def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None, 
     rcpp_threshold_reads arguments: thresholding is then done inside the tile kernel (pass_ is ignored)."""
     import torch
     import torch.distributed as dist
-    ranges, world, rank = _exchange_ranges(engine, "cx", group)
+    ranges, world, rank = _exchange_ranges(engine, "cx", group, ctx)
     dev = engine.device
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)

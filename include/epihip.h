@@ -223,8 +223,10 @@ void epi_pattern_table_free(epi_pattern_table *t);
  * its rows touch, (b) is told which keys are shared with other ranks; shared
  * tiles are accumulated into a dense counter slab instead of being emitted,
  * (c) the caller sum-reduces the slabs across ranks (RCCL all-reduce), and
- * (d) the owning rank emits them.  key = ((int64)rname << 32) | biased tile. */
-int epi_tile_positions(void);
+ * (d) the owning rank emits them.  key = ((int64)rname << 32) | biased tile.  Slab planes of one tile: (n, M) per
+ * strand and reported context, then the two strands' coverage difference arrays (cx_report.hip). */
+int epi_tile_positions(void);                  /* CX tile size for a single-context report (e.g. "Z") */
+int epi_cx_tile_positions(const char *ctx);    /* ... for this context string: 2048 with one reported context, else 1024 */
 int epi_batch_tile_key_range(epi_batch *b, void *stream, int64_t *first_key, int64_t *last_key);
 int epi_batch_cx_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned,
                             int32_t nshared, int32_t *d_slab /* [nshared][16][T] int32, zeroed by caller */);

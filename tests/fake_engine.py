@@ -19,10 +19,10 @@ class NumpyShardEngine:
         self.device = torch.device("cpu")
         self.n = t["off"].size - 1
 
-    def tile_positions(self):
+    def tile_positions(self, ctx="Z"):
         return T
 
-    def key_range(self, kind="cx"):
+    def key_range(self, kind="cx", ctx="Z"):
         if self.n == 0:
             return 0, -1
         t = self.t

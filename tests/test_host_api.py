@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     exported = set(re.findall(r" T (epi_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.epi_version() >= 100 and lib.epi_tile_positions() == 1024
+    assert lib.epi_version() >= 100 and lib.epi_tile_positions() == 2048 and lib.epi_cx_tile_positions(b"ZXH") == 1024
 
 
 def test_no_oracle_in_product_path():
