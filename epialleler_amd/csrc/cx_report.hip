@@ -41,7 +41,14 @@
 
 namespace epi {
 
-constexpr int CX_WG = 512;                    // threads per tile workgroup (8 wavefronts)
+#ifndef EPI_CX_WG                             // (EPI_CX_WG, EPI_CX_T1: timing builds vary them; the product uses these values)
+#define EPI_CX_WG 512
+#endif
+#ifndef EPI_CX_T1
+#define EPI_CX_T1 2048
+#endif
+constexpr int CX_WG = EPI_CX_WG;              // threads per tile workgroup (8 wavefronts)
+constexpr int CX_T1 = EPI_CX_T1;              // tile positions of single-context reports
 constexpr int CX_CH = 16;                     // bytes (= positions) of one position-aligned load
 constexpr int CX_FLUSH_ROWS = 255;            // u8 -> u16 fold interval: a row adds at most 1 per position and counter
 constexpr int CX_SLAB_COV = 12;               // slab planes [16][T]: 2*(strand*NP + p) + {0: n, 1: M}; 12, 13: coverage
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
 
 // Tile size: 2048 positions for a single reported context (40 KiB of LDS, four workgroups per CU, fewer rows that
 // reach into two tiles, fuller rounds), 1024 with two or three contexts (their counters take 32 / 44 KiB).
-static int cx_tile_for(int np) { return np <= 1 ? 2048 : 1024; }
+static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : 1024; }
 
 // Lanes per row and 16-byte chunks per lane.  Whole rows (fused thresholding) must fit one visit of G * NU chunks
 // wherever they start inside their first chunk; slices of longer rows loop.  Returned as G * 8 + NU.
@@ -821,15 +828,15 @@ static void launch_cx_g(bool heavy, int g, int nt, dim3 grid, hipStream_t s, con
 static void launch_cx(bool heavy, int np, bool fused, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   const int g = shape >> 3, nu = shape & 7;
   if (fused) {                                             // one context, 2048-position tiles
-    if (nu == 3) launch_cx_g<2048, 3, 1, true>(heavy, g, nt, grid, s, a);
-    else launch_cx_g<2048, 5, 1, true>(heavy, g, nt, grid, s, a);
-  } else if (np == 1) launch_cx_g<2048, 3, 1, false>(heavy, g, nt, grid, s, a);
+    if (nu == 3) launch_cx_g<CX_T1, 3, 1, true>(heavy, g, nt, grid, s, a);
+    else launch_cx_g<CX_T1, 5, 1, true>(heavy, g, nt, grid, s, a);
+  } else if (np == 1) launch_cx_g<CX_T1, 3, 1, false>(heavy, g, nt, grid, s, a);
   else if (np == 2) launch_cx_g<1024, 3, 2, false>(heavy, g, nt, grid, s, a);
   else launch_cx_g<1024, 3, 3, false>(heavy, g, nt, grid, s, a);
 }
 
 static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
-  if (np == 1) hipLaunchKernelGGL((k_cx_emit_slab<2048, 1>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
+  if (np == 1) hipLaunchKernelGGL((k_cx_emit_slab<CX_T1, 1>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
   else if (np == 2) hipLaunchKernelGGL((k_cx_emit_slab<1024, 2>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
   else hipLaunchKernelGGL((k_cx_emit_slab<1024, 3>), dim3((unsigned)nshared), dim3(CX_WG), 0, s, a, owned, slot_tile);
 }
