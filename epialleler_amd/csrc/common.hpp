@@ -108,6 +108,7 @@ struct epi_batch {
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
+  uint32_t mhlf_slot = 0;                      // ... and its fused kernel (1024-position tiles)
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes
   uint32_t cx_last_ctx_of_plane = 0;

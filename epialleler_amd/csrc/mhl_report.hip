@@ -994,6 +994,364 @@ __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ til
   }
 }
 
+// ---- fused kernel: pass 1 and pass 2 in ONE pass over the bytes -----------------------------------------------------------
+// For batches of short reads and a single haplotype context (generateMhlReport's default, ctx = "Zz") the tile
+// workgroup itself does the run-length analysis of every candidate row from the registers it has loaded (the body of
+// k_mhl_rows: bit planes, segmented lane scans, bit-parallel spans) and adds the results straight into LDS:
+//   * coverage as a difference array (+1 / -1 at the ends of the row; both strands packed in one dword; skipped and
+//     doubled codes corrected per byte),
+//   * n = calls of the context (either case) as u8 counters, four positions per dword: loads are position-aligned
+//     (16-byte chunks at any byte alignment), so a dword of xm is ONE ds_add_u32 instead of four,
+//   * the three sums (h, S(h), S(M)) as difference arrays, one interval per row / counted run / stretch piece.
+// Nothing is written to HBM between the two passes (no per-read info, no records) and xm is read once (rows that
+// reach into two tiles are analysed by both; the second visit is an L2 hit).  A row is emitted iff n > cov/2 (then no
+// other context can win the rule, :76-86).  Tiles with more than 255 candidate rows (u8 counters) or tiles shared
+// with other ranks make the caller fall back to the two-kernel path above.
+constexpr int MHLF_T = 1024, MHLF_WG = 512;
+
+struct MhlFArgs {
+  const uint8_t *xm;
+  const int64_t *off;
+  const int32_t *start, *strand;
+  int64_t xm_cap;                         // readable bytes behind xm
+  const Tile *tiles;
+  MhlLut lut;                             // flags: 1 member, 2 cut, 4 skipped, 8 / 16 out-of-context (un)methylated,
+                                          // 32 doubled (nibble 9), 64 / 128 / 192 stray nibble 3 / 4 / 8 (their counter IS a sum, :190)
+  int32_t hmin;
+  double max_oo;
+  uint32_t H, ctx;                        // haplotype window clamp (:112), reported context code
+  uint32_t *pool_key, *pool_cov;
+  unsigned long long *pool_hs, *pool_nu, *pool_de;
+  uint32_t pool_cap, slot_rows, ovf_base;
+  uint32_t *cursor, *tile_nrow, *tile_base;
+  uint32_t *deep;                         // tiles with too many candidate rows for this kernel (the caller falls back)
+  int max_rows;
+};
+
+struct __attribute__((packed, aligned(1))) MhlU4u { uint32_t x, y, z, w; };
+
+// the W = 16*C bytes at byte offset g0 (any alignment, may reach outside [0, cap) for the first / last rows)
+template <int C>
+__device__ __forceinline__ ChunkRaw<C> mhlf_chunk_load(const uint8_t *__restrict__ xm, int64_t cap, int64_t g0, int64_t rs, int64_t re) {
+  constexpr int W = 16 * C;
+  ChunkRaw<C> r;
+  r.lo = 0; r.hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4 * C; j++) r.ww[j] = 0u;
+  int64_t lo = rs - g0, hi = re - g0;
+  if (lo < 0) lo = 0;
+  if (hi > W) hi = W;
+  if (hi <= lo) return r;
+  r.lo = (int)lo; r.hi = (int)hi;
+  if (__builtin_expect(g0 < 0 || g0 + W > cap, 0)) {
+#pragma unroll
+    for (int j = 0; j < 4 * C; j++) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int64_t ad = g0 + 4 * j + q;
+        if (ad >= 0 && ad < cap) x |= (uint32_t)xm[ad] << (8 * q);
+      }
+      r.ww[j] = x;
+    }
+    return r;
+  }
+#pragma unroll
+  for (int j = 0; j < C; j++) {
+    if (j == 0 || g0 + 16 * j < re) {
+      const MhlU4u w = *reinterpret_cast<const MhlU4u *>(xm + g0 + 16 * j);
+      r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
+    }
+  }
+  return r;
+}
+
+// mhl_chunk_masks plus the LUT flags of every dword (bytes outside the row cleared)
+template <int C>
+__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhlf_chunk_masks(const ChunkRaw<C> &r, const MhlLut &lut, uint32_t (&f8)[4 * C]) {
+  using M = typename MaskOf<C>::T;
+  constexpr int W = 16 * C;
+  Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
+#pragma unroll
+  for (int d = 0; d < 4 * C; d++) f8[d] = 0u;
+  if (r.hi <= r.lo) return c;
+  const int lo = r.lo, hi = r.hi;
+  c.V = bm_below<M>(hi) & ~bm_below<M>(lo);
+  const bool edge = lo > 0 || hi < W;
+  uint32_t kacc = 0, cm = 0, cn = 0;
+  uint32_t ulo = 0, uhi = 0, llo = 0, lhi = 0;           // mask bits 0-31 / 32-63
+#pragma unroll
+  for (int e = 0; e < 2 * C; e++) {
+    uint32_t f[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int d = 2 * e + h;
+      const uint32_t lo3 = r.ww[d] & 0x07070707u;
+      const uint32_t pick = ((r.ww[d] >> 1) & 0x04040404u) | 0x03020100u;
+      uint32_t v = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
+                                         __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+      if (edge) {
+        int a = lo - 4 * d, b = hi - 4 * d;                   // valid bytes [a, b) of this dword
+        a = a < 0 ? 0 : (a > 4 ? 4 : a);
+        b = b < 0 ? 0 : (b > 4 ? 4 : b);
+        const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
+        v &= bm;
+      }
+      f[h] = v;
+      f8[d] = v;
+      kacc |= v;
+      cm = __builtin_amdgcn_udot4(v & 0x08080808u, 0x01010101u, cm, false);     // 8 x count
+      cn = __builtin_amdgcn_udot4(v & 0x10101010u, 0x01010101u, cn, false);     // 16 x count
+    }
+    const uint32_t ub = __builtin_amdgcn_udot4(f[1] & 0x01010101u, 0x80402010u,
+                                               __builtin_amdgcn_udot4(f[0] & 0x01010101u, 0x08040201u, 0u, false), false);
+    const uint32_t lb2 = __builtin_amdgcn_udot4(f[1] & 0x02020202u, 0x80402010u,
+                                                __builtin_amdgcn_udot4(f[0] & 0x02020202u, 0x08040201u, 0u, false), false);
+    const int sh = 8 * (e & 3);
+    if (e < 4) { ulo |= ub << sh; llo |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
+    else { uhi |= ub << sh; lhi |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
+  }
+  c.U = (M)ulo; c.L = (M)llo;
+  if constexpr (sizeof(M) == 8) { c.U |= (M)uhi << 32; c.L |= (M)lhi << 32; }
+  c.oom = cm >> 3;
+  c.oou = cn >> 4;
+  if (kacc & 0x04040404u) {
+#pragma unroll
+    for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
+  }
+  return c;
+}
+
+// calls fn(first bit, length, m) for every run of set bits (m as write_runs computes it)
+template <int W, class M, class FN>
+__device__ __forceinline__ void mhlf_for_runs(M bits, bool stretch, const Chunk<M> &c, uint32_t enter, uint32_t cont, FN fn) {
+  while (bits) {
+    const int f = bm_ctz(bits);
+    const M t = ~(bits >> f);
+    const int e = t ? bm_ctz(t) : (int)(8 * sizeof(M)) - f;    // run length
+    uint32_t m = 0;
+    if (stretch) {
+      const M lc = c.L & bm_below<M>(f);
+      const int a = lc ? bm_msb(lc) + 1 : 0;                   // segment = bits [a, b) between the surrounding cuts
+      const int end = f + e;
+      const M hc = end < W ? (c.L >> end) : (M)0;
+      const int b = hc ? end + bm_ctz(hc) : W;
+      const M segmask = bm_below<M>(b) & ~bm_below<M>(a);
+      m = (a == 0 ? enter : 0u) + (uint32_t)bm_popc(c.U & segmask) + (b == W ? cont : 0u);
+    }
+    fn(f, e, m);
+    bits &= ~(bm_below<M>(e) << f);
+  }
+}
+
+// +v on tile positions [a, b) of one (unpadded) difference array of MHLF_T entries
+template <class ST>
+__device__ __forceinline__ void mhlf_interval(ST *d, int a, int b, unsigned long long v) {
+  if (a < 0) a = 0;
+  if (a < b && a < MHLF_T) {
+    atomicAdd(d + a, (ST)v);
+    if (b < MHLF_T) atomicAdd(d + b, (ST)0 - (ST)v);
+  }
+}
+
+template <class ST> constexpr int mhlf_waves_per_simd() { return sizeof(ST) == 4 ? 8 : 4; }   // 38 / 62 KiB of LDS per workgroup
+
+template <int G, int C, class ST>
+__global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fused(MhlFArgs a, int ntiles) {
+  using M = typename MaskOf<C>::T;
+  constexpr int W = 16 * C, T = MHLF_T, Q = T / 4, R = 64 / G, NW = MHLF_WG / 64;
+  __shared__ __attribute__((aligned(16))) uint32_t s_n8[2 * Q];        // [strand][Q]: calls of the context, u8 x 4 positions
+  __shared__ __attribute__((aligned(16))) uint32_t s_cov[T];           // coverage difference array, '+' low half, '-' high half
+  __shared__ __attribute__((aligned(16))) ST s_sum[6 * T];             // [sum: S(M), h, S(h)][strand][T] difference arrays
+  __shared__ uint32_t s_scan[NW + 2];
+  __shared__ ST s_tot[6][NW];
+  __shared__ uint32_t s_ctot[NW];
+  const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const Tile td = a.tiles[tile];
+  {
+    uint4 *z = reinterpret_cast<uint4 *>(s_n8);
+    for (int i = threadIdx.x; i < 2 * Q / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+    z = reinterpret_cast<uint4 *>(s_cov);
+    for (int i = threadIdx.x; i < T / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+    z = reinterpret_cast<uint4 *>(s_sum);
+    for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  if (td.row_hi - td.row_lo > a.max_rows || td.slot >= 0) {
+    if (threadIdx.x == 0) { atomicAdd(a.deep, 1u); a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+    return;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G;
+
+  // ---- accumulate: G lanes own a row, W contiguous bytes per lane ----
+  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
+    const int r = rbase + grp;
+    const bool valid = r < td.row_hi;
+    int64_t rs = 0, re = 0;
+    int32_t st = 0, sd = 1;
+    if (valid) { rs = a.off[r]; re = a.off[r + 1]; st = a.start[r]; sd = a.strand[r]; }
+    const int32_t rel = (int32_t)((uint32_t)st - (uint32_t)td.pos0);       // tile position of the row's byte 0
+    const int32_t len = (int32_t)(re - rs);
+    const int32_t P0 = rel - (rel & 15) + sub * W;                          // tile position of this lane's byte 0 (multiple of 16)
+    const int64_t g0 = rs - (rel & 15) + (int64_t)sub * W;                  // its byte offset in xm
+    uint32_t f8[4 * C];
+    const ChunkRaw<C> raw = valid ? mhlf_chunk_load<C>(a.xm, a.xm_cap, g0, rs, re) : ChunkRaw<C>{{0}, 0, 0};
+    const Chunk<M> c = mhlf_chunk_masks<C>(raw, a.lut, f8);
+
+    // members of the open segment to the left (enter) and to the right (cont) of this lane
+    Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
+    seg_scan_steps<G, 1>(pf, sf, sub);
+    uint32_t enter = grp_up<G, 1>(pf.cnt), cont = grp_down<G, 1>(sf.cnt);
+    if (sub == 0) enter = 0u;
+    if (sub == G - 1) cont = 0u;
+    const uint32_t h = grp_sum<G / 2>((uint32_t)bm_popc(c.U | c.L)), oo_m = grp_sum<G / 2>(c.oom), oo_u = grp_sum<G / 2>(c.oou);
+    const uint32_t anyk = grp_or<G / 2>(c.K ? 1u : 0u);
+    const bool keep = valid && len > 0 && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);      // :176-179
+    if (keep) {
+      const int sidx = sd - 1;
+      const unsigned long long sh = mhl_lut(h, a.H);                         // S(h), :194
+      ST *dn = s_sum + (0 + sidx) * T, *dh = s_sum + (2 + sidx) * T, *dd = s_sum + (4 + sidx) * T;
+      const uint32_t unit = sidx ? 65536u : 1u;
+      if (sub == 0) {
+        mhlf_interval(s_cov, rel, rel + len, unit);                          // coverage of the whole row; skipped bytes corrected below
+        if (!anyk) {                                                         // every byte counted: one interval per sum (:192, :194)
+          mhlf_interval(dh, rel, rel + len, (unsigned long long)h);
+          mhlf_interval(dd, rel, rel + len, sh);
+        }
+      }
+      // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
+      const M P = span_bits<W>(c, enter, cont);
+      mhlf_for_runs<W>(P, true, c, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(dn, P0 + f, P0 + f + e, mhl_lut(m, a.H)); });
+      if (anyk) {                                                            // reads with skipped bytes: h and S(h) per counted run
+        const M Qr = c.V & ~c.K;
+        mhlf_for_runs<W>(Qr, false, c, enter, cont, [&](int f, int e, uint32_t) {
+          mhlf_interval(dh, P0 + f, P0 + f + e, (unsigned long long)h);
+          mhlf_interval(dd, P0 + f, P0 + f + e, sh);
+        });
+      }
+      // calls of the context: u8 counters, one ds_add_u32 per dword that holds any
+      uint32_t *n8 = s_n8 + sidx * Q + (P0 >> 2);
+      uint32_t fl = 0;
+#pragma unroll
+      for (int d = 0; d < 4 * C; d++) {
+        const uint32_t nb = (f8[d] | (f8[d] >> 1)) & 0x01010101u;
+        fl |= f8[d];
+        if (nb != 0u && (uint32_t)((P0 >> 2) + d) < (uint32_t)Q) atomicAdd(n8 + d, nb);
+      }
+      // rare bytes: skipped (coverage -1), nibble 9 (coverage +1), stray nibbles 3 / 4 / 8 (+1 on the sum their counter is)
+      if (__builtin_expect((fl & 0xE4E4E4E4u) != 0u, 0)) {
+#pragma unroll
+        for (int d = 0; d < 4 * C; d++) {
+          if ((f8[d] & 0xE4E4E4E4u) == 0u) continue;
+          for (int j = 0; j < 4; j++) {
+            const uint32_t fb = (f8[d] >> (8 * j)) & 0xE4u;
+            if (!fb) continue;
+            const int p = P0 + 4 * d + j;
+            if (fb & 4u) mhlf_interval(s_cov, p, p + 1, (unsigned long long)(0u - unit));
+            if (fb & 32u) mhlf_interval(s_cov, p, p + 1, unit);
+            const uint32_t sid = fb >> 6;
+            if (sid == 1u) mhlf_interval(dn, p, p + 1, 1ull);
+            else if (sid == 2u) mhlf_interval(dd, p, p + 1, 1ull);
+            else if (sid == 3u) mhlf_interval(dh, p, p + 1, 1ull);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- emit: prefix sums of the seven difference arrays (two consecutive positions per thread), rule, ordered rows ----
+  const int p0 = 2 * (int)threadIdx.x;
+  uint32_t cv[2] = {s_cov[p0], s_cov[p0 + 1]};
+  cv[1] += cv[0];
+  ST sv[6][2];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { sv[k][0] = s_sum[k * T + p0]; sv[k][1] = sv[k][0] + s_sum[k * T + p0 + 1]; }
+  const uint32_t cinc = wave_scan_u32(cv[1]);
+  ST sinc[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) sinc[k] = mhl_wave_scan<ST>(sv[k][1]);
+  if (lane == 63) {
+    s_ctot[wave] = cinc;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s_tot[k][wave] = sinc[k];
+  }
+  __syncthreads();
+  uint32_t cbefore = cinc - cv[1];
+  ST sbefore[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) sbefore[k] = sinc[k] - sv[k][1];
+  for (int w = 0; w < wave; w++) {
+    cbefore += s_ctot[w];
+#pragma unroll
+    for (int k = 0; k < 6; k++) sbefore[k] += s_tot[k][w];
+  }
+  uint32_t key[4], ncall[4];
+  unsigned long long hs[4], nu[4], de[4];
+  bool ok[4];
+  int nr = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {                              // key order: position, then '+' before '-'
+    const int j = i >> 1, s = i & 1, p = p0 + j;
+    const uint32_t cvv = cv[j] + cbefore;
+    const uint32_t cov = s ? cvv >> 16 : cvv & 0xFFFFu;
+    const uint32_t n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
+    ok[i] = n > (cov >> 1);                                  // :76-86: the context wins the rule iff its calls exceed half the coverage
+    key[i] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | a.ctx;
+    ncall[i] = n;                                            // coverage column, :90
+    nu[i] = (unsigned long long)(sv[0 + s][j] + sbefore[0 + s]);
+    hs[i] = (unsigned long long)(sv[2 + s][j] + sbefore[2 + s]);
+    de[i] = (unsigned long long)(sv[4 + s][j] + sbefore[4 + s]);
+    nr += ok[i];
+  }
+  uint32_t inc = (uint32_t)nr, wtot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned long long bi = __ballot(ok[i]);
+    inc += __builtin_amdgcn_mbcnt_hi((uint32_t)(bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bi, 0u));
+    wtot += (uint32_t)__popcll(bi);
+  }
+  if (lane == 0) s_scan[wave] = wtot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
+    uint32_t base = 0;
+    bool fits = true;
+    if (acc) {
+      if (acc <= a.slot_rows) base = (uint32_t)tile * a.slot_rows;
+      else {
+        const uint32_t o = atomicAdd(a.cursor, acc);
+        fits = (uint64_t)a.ovf_base + o + acc <= a.pool_cap;
+        base = a.ovf_base + o;
+      }
+    }
+    s_scan[NW + 1] = base;
+    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
+    a.tile_nrow[tile] = acc;
+    a.tile_base[tile] = base;
+  }
+  __syncthreads();
+  const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
+  if (total != 0xFFFFFFFFu) {
+    uint32_t w = base + inc - (uint32_t)nr + s_scan[wave];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (ok[i]) {
+        a.pool_key[w] = key[i];
+        a.pool_cov[w] = ncall[i];
+        a.pool_hs[w] = hs[i];
+        a.pool_nu[w] = nu[i];
+        a.pool_de[w] = de[i];
+        w++;
+      }
+    }
+  }
+}
+
 static size_t mhl_pool_rows(const epi_batch *b) { return b->pool_cap < b->pool_cap2 ? b->pool_cap : b->pool_cap2; }
 
 static int ensure_mhl_pool(epi_batch *b, size_t rows) {
@@ -1093,6 +1451,117 @@ static MhlLut make_mhl_lut(uint32_t ctx_mask) {
   return l;
 }
 
+// nibble -> flags of the fused kernel (MhlFArgs::lut)
+static MhlLut make_mhlf_lut(uint32_t ctx_mask) {
+  MhlLut l = make_mhl_lut(ctx_mask);
+  uint32_t *w[4] = {&l.lo0, &l.lo1, &l.hi0, &l.hi1};
+  auto add = [&](uint32_t code, uint32_t f) { *w[code >> 2] |= f << (8 * (code & 3)); };
+  add(9, 32u);                                             // counts twice in the coverage (its counter is the coverage slot, :191)
+  add(3, 64u); add(4, 128u); add(8, 192u);                 // their counters are the sums of :193, :194, :192
+  return l;
+}
+
+template <class ST>
+static void launch_mhl_fused(int gc, int nt, hipStream_t s, const MhlFArgs &a) {
+  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
+#define EPI_LAUNCH(GG)                                                                                              \
+  case GG * 8 + 2: hipLaunchKernelGGL((k_mhl_fused<GG, 2, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
+  case GG * 8 + 3: hipLaunchKernelGGL((k_mhl_fused<GG, 3, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
+  case GG * 8 + 4: hipLaunchKernelGGL((k_mhl_fused<GG, 4, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+  switch (gc) {
+    EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
+    default: break;
+  }
+#undef EPI_LAUNCH
+}
+
+// The fused path (k_mhl_fused).  *done = false: the batch is not eligible, or a tile turned out too deep -- the caller
+// runs the two-kernel path instead.
+static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, double max_oo, hipStream_t s,
+                            int64_t *nrow_out, bool *done) {
+  *done = false;
+  static int enabled = -1;                                 // test hook: EPIHIP_MHL_FUSED=0 keeps every batch on the two-kernel path
+  if (enabled < 0) { enabled = 1; if (const char *env = getenv("EPIHIP_MHL_FUSED")) enabled = atoi(env) != 0; }
+  if (!enabled || !b->shared_keys.empty()) return EPI_OK;
+  uint32_t k = 0;
+  for (uint32_t c : {2u, 6u, 7u}) if (ctx_mask == ((1u << c) | (1u << (c + 8)))) k = c;
+  if (!k) return EPI_OK;                                   // one context, both cases (generateMhlReport's "Zz", "Xx", "Hh")
+  constexpr int T = MHLF_T;
+  RowStats st;
+  int32_t nt = 0;
+  EPI_TRY(build_tiles(b, s, T, &st, &nt));
+  const int gc = pick_mhl_group(st.max_len);
+  if (gc == 0 || getenv("EPIHIP_MHL_GROUP")) return EPI_OK;  // reads longer than one block of lanes: wavefront-per-read path
+  b->last_ntiles = nt;
+  if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; *done = true; return EPI_OK; }
+  // u32 LDS sums while 255 rows of the largest possible value stay below 2^31 (h <= read length)
+  uint32_t hcap = (uint32_t)st.max_len > 65535u ? 65535u : (uint32_t)st.max_len;
+  if (hcap >= H) hcap = H;
+  const unsigned long long vmax = nrS(hcap) > 1 ? nrS(hcap) : 1;
+  const bool narrow = ((1ull << 31) - 1) / (vmax + 2) >= 255;
+  EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
+  EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
+  EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
+  uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc layout as in the CX report: [1] cursor, [2] rows, [3] deep tiles
+  if (!b->mhlf_slot) b->mhlf_slot = T / 8;
+  uint32_t slot = b->mhlf_slot > 2u * T ? 2u * T : b->mhlf_slot;
+  if (const char *env = getenv("EPIHIP_MHL_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }   // test hook
+  while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;
+  size_t ovf_base = (size_t)nt * slot;
+  for (;;) {
+    const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
+    if (mhl_pool_rows(b) >= ovf_base + ovf) break;
+    const int rc = ensure_mhl_pool(b, ovf_base + ovf);
+    if (rc == EPI_OK) break;
+    b->pool_cap = 0; b->pool_cap2 = 0;
+    if (!slot) return rc;
+    slot = 0;
+    ovf_base = 0;
+  }
+  MhlFArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xm = b->xm; a.off = b->off; a.start = b->start; a.strand = b->strand;
+  a.xm_cap = (b->nbytes + 15) / 16 * 16;
+  a.tiles = b->tiles.as<Tile>();
+  a.lut = make_mhlf_lut(ctx_mask);
+  a.hmin = (int32_t)hmin; a.max_oo = max_oo; a.H = H; a.ctx = k;
+  a.cursor = cursor;
+  a.tile_nrow = b->tile_nrow.as<uint32_t>();
+  a.tile_base = b->tile_base.as<uint32_t>();
+  a.deep = b->misc.as<uint32_t>() + 3;
+  a.max_rows = 255;
+  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0 && v < 255) a.max_rows = v; }   // test hook
+  a.slot_rows = slot;
+  a.ovf_base = (uint32_t)ovf_base;
+  EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, MHLF_WG, "lMHL tile kernel"));
+  uint32_t host[3] = {0, 0, 0};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    a.pool_key = b->pool_key.as<uint32_t>();
+    a.pool_cov = b->pool_a.as<uint32_t>();
+    a.pool_hs = b->pool_d.as<unsigned long long>();
+    a.pool_nu = b->pool_e.as<unsigned long long>();
+    a.pool_de = b->pool_f.as<unsigned long long>();
+    a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
+    if (attempt > 0) EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));
+    prof_begin("mhl_tiles", s);
+    if (narrow) launch_mhl_fused<uint32_t>(gc, nt, s, a); else launch_mhl_fused<unsigned long long>(gc, nt, s, a);
+    prof_end("mhl_tiles", s);
+    EPI_HIP(hipGetLastError());
+    EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
+    EPI_TRY(read_scalars(b, s, cursor, 12, host));         // {overflow rows handed out, total rows, deep tiles}
+    if (host[2] > 0) return EPI_OK;                        // a tile with more rows than u8 counters take: two-kernel path
+    if (ovf_base + host[0] <= a.pool_cap) break;
+    if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
+    EPI_TRY(ensure_mhl_pool(b, ovf_base + host[0] + (host[0] >> 4) + 1024));
+  }
+  if (host[0] > host[1] / 8 && b->mhlf_slot < 2u * T) b->mhlf_slot *= 2;
+  b->last_kind = 2;
+  b->last_nrow = host[1];
+  *nrow_out = host[1];
+  *done = true;
+  return EPI_OK;
+}
+
 }  // namespace epi
 
 using namespace epi;
@@ -1109,6 +1578,12 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   uint32_t ctx_mask = 0;                                                     // :104-107
   for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
   const uint32_t H = hmax > 0 ? (hmax < 65536 ? (uint32_t)hmax : 65536u) : 65536u;   // :112
+
+  {                                                        // short reads, one haplotype context: one pass over the bytes
+    bool done = false;
+    EPI_TRY(mhl_fused_report(b, ctx_mask, H, hmin, max_ooctx_meth_frac, s, nrow_out, &done));
+    if (done) return EPI_OK;
+  }
 
   RowStats st;
   int32_t nt = 0;

@@ -18,13 +18,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot
     {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
-    {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL: nearly every tile outgrows its pool slot
+    {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL (fused kernel): nearly every tile outgrows its pool slot
     {"EPIHIP_MHL_SLOT": "0"},
-    {"EPIHIP_MHL_WG": "512", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL tile kernel with 512-thread workgroups for short reads too
+    {"EPIHIP_HEAVY_ROWS": "40"},                                         # fused lMHL kernel gives up on tiles with > 40 rows: two-kernel path
+    {"EPIHIP_MHL_FUSED": "0"},                                           # lMHL: the two-kernel path (records) for every batch
+    {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},
+    {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_SLOT": "0"},
+    {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_WG": "512", "EPIHIP_HEAVY_ROWS": "500"},   # lMHL tile kernel with 512-thread workgroups for short reads too
     {"EPIHIP_MHL_WG": "256", "EPIHIP_MHL_MULTI": "1"},                   # ... and 256 with the per-block records of long reads
     {"EPIHIP_MHL_MULTI": "1"},                                           # lMHL pass 1: wavefront-per-read kernel for every read
     {"EPIHIP_MHL_MULTI": "1", "EPIHIP_MHL_TILE_GROUP": "64", "EPIHIP_HEAVY_ROWS": "500"},
-    {"EPIHIP_MHL_SUMS": "64", "EPIHIP_HEAVY_ROWS": "500"},              # lMHL pass 2 with u64 LDS sums where u32 would do
+    {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_SUMS": "64", "EPIHIP_HEAVY_ROWS": "500"},   # lMHL pass 2 with u64 LDS sums where u32 would do
 ])
 def test_cx_kernel_variants(env):
     e = dict(os.environ)
