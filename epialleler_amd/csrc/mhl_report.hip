@@ -1066,20 +1066,20 @@ __device__ __forceinline__ ChunkRaw<C> mhlf_chunk_load(const uint8_t *__restrict
   return r;
 }
 
-// mhl_chunk_masks plus the LUT flags of every dword (bytes outside the row cleared)
+// Bit planes of a lane's W bytes for the fused kernel.  The LUT flags of bytes outside the row are NOT cleared dword by
+// dword (two of the eight lanes of a row hold an edge, so the masking code ran in every wavefront step): the planes
+// are ANDed with the valid-byte mask V instead, and the out-of-context counts are popcounts of masked planes.  f8 keeps
+// the raw flags (rare skip / double / stray bytes: their handler checks V itself).
 template <int C>
 __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhlf_chunk_masks(const ChunkRaw<C> &r, const MhlLut &lut, uint32_t (&f8)[4 * C]) {
   using M = typename MaskOf<C>::T;
-  constexpr int W = 16 * C;
   Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
 #pragma unroll
   for (int d = 0; d < 4 * C; d++) f8[d] = 0u;
   if (r.hi <= r.lo) return c;
-  const int lo = r.lo, hi = r.hi;
-  c.V = bm_below<M>(hi) & ~bm_below<M>(lo);
-  const bool edge = lo > 0 || hi < W;
-  uint32_t kacc = 0, cm = 0, cn = 0;
-  uint32_t ulo = 0, uhi = 0, llo = 0, lhi = 0;           // mask bits 0-31 / 32-63
+  c.V = bm_below<M>(r.hi) & ~bm_below<M>(r.lo);
+  uint32_t kacc = 0;
+  uint32_t ulo = 0, uhi = 0, llo = 0, lhi = 0, mlo = 0, mhi = 0, nlo = 0, nhi = 0;   // mask bits 0-31 / 32-63 of U, L, oo meth, oo unmeth
 #pragma unroll
   for (int e = 0; e < 2 * C; e++) {
     uint32_t f[2];
@@ -1088,38 +1088,49 @@ __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhlf_chunk_masks(const C
       const int d = 2 * e + h;
       const uint32_t lo3 = r.ww[d] & 0x07070707u;
       const uint32_t pick = ((r.ww[d] >> 1) & 0x04040404u) | 0x03020100u;
-      uint32_t v = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3),
-                                         __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
-      if (edge) {
-        int a = lo - 4 * d, b = hi - 4 * d;                   // valid bytes [a, b) of this dword
-        a = a < 0 ? 0 : (a > 4 ? 4 : a);
-        b = b < 0 ? 0 : (b > 4 ? 4 : b);
-        const uint32_t bm = b > a ? ((b >= 4 ? ~0u : ((1u << (8 * b)) - 1u)) & ~((1u << (8 * a)) - 1u)) : 0u;
-        v &= bm;
-      }
-      f[h] = v;
-      f8[d] = v;
-      kacc |= v;
-      cm = __builtin_amdgcn_udot4(v & 0x08080808u, 0x01010101u, cm, false);     // 8 x count
-      cn = __builtin_amdgcn_udot4(v & 0x10101010u, 0x01010101u, cn, false);     // 16 x count
+      f[h] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3), __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
+      f8[d] = f[h];
+      kacc |= f[h];
     }
-    const uint32_t ub = __builtin_amdgcn_udot4(f[1] & 0x01010101u, 0x80402010u,
-                                               __builtin_amdgcn_udot4(f[0] & 0x01010101u, 0x08040201u, 0u, false), false);
-    const uint32_t lb2 = __builtin_amdgcn_udot4(f[1] & 0x02020202u, 0x80402010u,
-                                                __builtin_amdgcn_udot4(f[0] & 0x02020202u, 0x08040201u, 0u, false), false);
+    // flag bit b of eight bytes -> eight mask bits, scaled by 2^b: v_dot4_u32_u8 with weights 1..8 / 16..128
+    auto plane = [&](uint32_t bit) {
+      return __builtin_amdgcn_udot4(f[1] & (0x01010101u * bit), 0x80402010u,
+                                    __builtin_amdgcn_udot4(f[0] & (0x01010101u * bit), 0x08040201u, 0u, false), false);
+    };
+    const uint32_t ub = plane(1u), lb = plane(2u) >> 1, mb = plane(8u) >> 3, nb = plane(16u) >> 4;
     const int sh = 8 * (e & 3);
-    if (e < 4) { ulo |= ub << sh; llo |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
-    else { uhi |= ub << sh; lhi |= sh ? lb2 << (sh - 1) : lb2 >> 1; }
+    if (e < 4) { ulo |= ub << sh; llo |= lb << sh; mlo |= mb << sh; nlo |= nb << sh; }
+    else { uhi |= ub << sh; lhi |= lb << sh; mhi |= mb << sh; nhi |= nb << sh; }
   }
+  M om = (M)mlo, ou = (M)nlo;
   c.U = (M)ulo; c.L = (M)llo;
-  if constexpr (sizeof(M) == 8) { c.U |= (M)uhi << 32; c.L |= (M)lhi << 32; }
-  c.oom = cm >> 3;
-  c.oou = cn >> 4;
-  if (kacc & 0x04040404u) {
+  if constexpr (sizeof(M) == 8) { c.U |= (M)uhi << 32; c.L |= (M)lhi << 32; om |= (M)mhi << 32; ou |= (M)nhi << 32; }
+  c.U &= c.V; c.L &= c.V;
+  c.oom = (uint32_t)bm_popc(om & c.V);
+  c.oou = (uint32_t)bm_popc(ou & c.V);
+  if (kacc & 0x04040404u) {                                   // skipped bytes are rare ('+'/'-', filler between mates)
 #pragma unroll
     for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
+    c.K &= c.V;
   }
   return c;
+}
+
+// span_bits with the two segmented fills done by carry propagation instead of log-step shifts: adding the member
+// bits to the mask of non-cut bytes lets a carry run upward through a segment until the next cut absorbs it; the
+// bits it flips (plus the members themselves) are the bytes at or above a member of their segment.  The downward fill
+// is the same on the bit-reversed words.
+__device__ __forceinline__ uint64_t mhlf_fill_up(uint64_t x, uint64_t m) {       // m: propagatable bits, x subset of m
+  return ((((x + m) ^ m) & m) | x);
+}
+template <int W, class M>
+__device__ __forceinline__ M mhlf_span_bits(const Chunk<M> &c, uint32_t enter, uint32_t cont) {
+  const uint64_t nl = (uint64_t)(~c.L & bm_below<M>(W));                       // non-cut bytes of the lane
+  const uint64_t x = (uint64_t)c.U | ((enter > 0u && !(c.L & (M)1)) ? 1ull : 0ull);
+  const uint64_t y = (uint64_t)c.U | ((cont > 0u && !((c.L >> (W - 1)) & (M)1)) ? (1ull << (W - 1)) : 0ull);
+  const uint64_t up = mhlf_fill_up(x, nl);
+  const uint64_t dn = __brevll(mhlf_fill_up(__brevll(y), __brevll(nl)));
+  return (M)(up & dn & nl) & ~c.K & c.V;
 }
 
 // calls fn(first bit, length, m) for every run of set bits (m as write_runs computes it)
@@ -1186,19 +1197,29 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
 
-  // ---- accumulate: G lanes own a row, W contiguous bytes per lane ----
+  // ---- accumulate: G lanes own a row, W contiguous bytes per lane; the next step's row columns are fetched early ----
+  int64_t n_rs = 0, n_re = 0;
+  int32_t n_st = 0, n_sd = 1;
+  {
+    const int r0 = td.row_lo + wave * R + grp;
+    if (r0 < td.row_hi) { n_rs = a.off[r0]; n_re = a.off[r0 + 1]; n_st = a.start[r0]; n_sd = a.strand[r0]; }
+  }
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
     const int r = rbase + grp;
     const bool valid = r < td.row_hi;
-    int64_t rs = 0, re = 0;
-    int32_t st = 0, sd = 1;
-    if (valid) { rs = a.off[r]; re = a.off[r + 1]; st = a.start[r]; sd = a.strand[r]; }
+    const int64_t rs = n_rs, re = n_re;
+    const int32_t st = n_st, sd = n_sd;
     const int32_t rel = (int32_t)((uint32_t)st - (uint32_t)td.pos0);       // tile position of the row's byte 0
     const int32_t len = (int32_t)(re - rs);
     const int32_t P0 = rel - (rel & 15) + sub * W;                          // tile position of this lane's byte 0 (multiple of 16)
     const int64_t g0 = rs - (rel & 15) + (int64_t)sub * W;                  // its byte offset in xm
     uint32_t f8[4 * C];
     const ChunkRaw<C> raw = valid ? mhlf_chunk_load<C>(a.xm, a.xm_cap, g0, rs, re) : ChunkRaw<C>{{0}, 0, 0};
+    {
+      const int rn = r + NW * R;                                            // (in flight with the bytes)
+      n_rs = 0; n_re = 0; n_st = 0; n_sd = 1;
+      if (rn < td.row_hi) { n_rs = a.off[rn]; n_re = a.off[rn + 1]; n_st = a.start[rn]; n_sd = a.strand[rn]; }
+    }
     const Chunk<M> c = mhlf_chunk_masks<C>(raw, a.lut, f8);
 
     // members of the open segment to the left (enter) and to the right (cont) of this lane
@@ -1223,7 +1244,7 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
         }
       }
       // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
-      const M P = span_bits<W>(c, enter, cont);
+      const M P = mhlf_span_bits<W>(c, enter, cont);
       mhlf_for_runs<W>(P, true, c, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(dn, P0 + f, P0 + f + e, mhl_lut(m, a.H)); });
       if (anyk) {                                                            // reads with skipped bytes: h and S(h) per counted run
         const M Qr = c.V & ~c.K;
@@ -1232,12 +1253,15 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
           mhlf_interval(dd, P0 + f, P0 + f + e, sh);
         });
       }
-      // calls of the context: u8 counters, one ds_add_u32 per dword that holds any
+      // calls of the context: u8 counters, one ds_add_u32 per dword that holds any (the nibble of the in-context plane
+      // spread to four bytes by one multiplication)
       uint32_t *n8 = s_n8 + sidx * Q + (P0 >> 2);
+      const uint64_t N = (uint64_t)(c.U | c.L);
       uint32_t fl = 0;
 #pragma unroll
       for (int d = 0; d < 4 * C; d++) {
-        const uint32_t nb = (f8[d] | (f8[d] >> 1)) & 0x01010101u;
+        const uint32_t nib = (uint32_t)(N >> (4 * d)) & 15u;
+        const uint32_t nb = (nib * 0x00204081u) & 0x01010101u;
         fl |= f8[d];
         if (nb != 0u && (uint32_t)((P0 >> 2) + d) < (uint32_t)Q) atomicAdd(n8 + d, nb);
       }
@@ -1248,7 +1272,7 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
           if ((f8[d] & 0xE4E4E4E4u) == 0u) continue;
           for (int j = 0; j < 4; j++) {
             const uint32_t fb = (f8[d] >> (8 * j)) & 0xE4u;
-            if (!fb) continue;
+            if (!fb || !(((uint64_t)c.V >> (4 * d + j)) & 1ull)) continue;    // (flags of bytes outside the row are not cleared)
             const int p = P0 + 4 * d + j;
             if (fb & 4u) mhlf_interval(s_cov, p, p + 1, (unsigned long long)(0u - unit));
             if (fb & 32u) mhlf_interval(s_cov, p, p + 1, unit);
