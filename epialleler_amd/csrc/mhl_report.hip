@@ -93,7 +93,6 @@ struct RowsArgs {
                                           // may run past its region's capacity rec_cap / MHL_REGIONS: the caller regrows and reruns
   uint32_t *cont;                         // multi: members entering a block from the right
   uint32_t *max_h;                        // largest haplotype size among the kept reads (sizes the LDS sums of pass 2)
-  int ablate;                             // timing experiments only (EPIHIP_MHL_ABLATE >> 8)
 };
 
 // Per-byte bit masks of the 16*C bytes a lane owns: u32 for C = 2, u64 for C = 3, 4.
@@ -348,8 +347,8 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   const uint32_t anyk = grp_or<G / 2>(c.K ? 1u : 0u);
   const bool keep = valid && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);
   // the current maximum is read from L2 (an L1 copy would stay 0 and every read would issue the atomic: 67 ms)
-  if (keep && sub == 0 && !(a.ablate & 8) && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
-  const M P = (keep && !(a.ablate & 4)) ? span_bits<W>(c, enter, cont) : (M)0;
+  if (keep && sub == 0 && h > __hip_atomic_load(a.max_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_h, h);
+  const M P = keep ? span_bits<W>(c, enter, cont) : (M)0;
   const M Q = (keep && anyk) ? (c.V & ~c.K) : (M)0;
   const uint32_t nrec = run_count(P) + run_count(Q);
 
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
     for (int w = 0; w < 4; w++) { const uint32_t t = s_w[w]; s_w[w] = acc; acc += t; }
     const uint32_t region = blockIdx.x & (MHL_REGIONS - 1), region_cap = a.rec_cap / MHL_REGIONS;
     unsigned long long base = 0;
-    if (acc && !(a.ablate & 1)) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)acc);
+    if (acc) base = atomicAdd(a.rec_cursor + region * MHL_CUR_STRIDE, (unsigned long long)acc);
     s_w[4] = (base + acc <= (unsigned long long)region_cap) ? region * region_cap + (uint32_t)base : 0xFFFFFFFFu;   // does not fit: count only
   }
   __syncthreads();
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   const uint32_t row_n = grp_sum<G / 2>(nrec);
   if (valid && sub == 0)
     a.rowinfo[row] = make_int4(keep ? (int32_t)h : -1, (int32_t)anyk, (int32_t)my, base == 0xFFFFFFFFu ? 0 : (int32_t)row_n);
-  if (nrec && base != 0xFFFFFFFFu && !(a.ablate & 2)) {
+  if (nrec && base != 0xFFFFFFFFu) {
     const uint32_t off0 = (uint32_t)(g0 - rs);               // row offset of the chunk's byte 0 (wraps for the first chunk)
     MhlRec *out = a.recs + my;
     write_runs<W>(P, true, c, enter, cont, off0, out);
@@ -498,7 +497,6 @@ struct MhlArgs {
   const MhlRec *recs;
   uint32_t rec_cap;
   int multi;                              // records are kept per 2 KiB block of a row (k_mhl_rows_multi)
-  int ablate;                             // timing experiments only (EPIHIP_MHL_ABLATE)
   const Tile *tiles;
   uint32_t ctx_mask, H;
   uint32_t *pool_key, *pool_cov;
@@ -677,7 +675,7 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
       ST *dn = L.sums + MHL_DN + cur.sidx * MHL_SLEN;
       ST *dh = L.sums + MHL_DH + cur.sidx * MHL_SLEN;
       ST *dd = L.sums + MHL_DD + cur.sidx * MHL_SLEN;
-      if (!(cur.hs >> 31) && sub == 0 && !(a.ablate & 4)) {   // every byte of the slice is counted: one interval per sum
+      if (!(cur.hs >> 31) && sub == 0) {   // every byte of the slice is counted: one interval per sum
         mhl_interval(dh, cur.pf, cur.pe, (unsigned long long)h);
         mhl_interval(dd, cur.pf, cur.pe, sh);
       }
@@ -686,7 +684,7 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
         if (rec.m) mhl_interval(dn, ta, tb, mhl_lut(rec.m, a.H));
         else { mhl_interval(dh, ta, tb, (unsigned long long)h); mhl_interval(dd, ta, tb, sh); }
       };
-      if (!(a.ablate & 2)) {
+      {
         for (uint32_t k = (uint32_t)sub; k < cur.rn; k += G) add_rec(a.recs[cur.rb + k]);
         if (a.multi) {                                         // long reads: records are kept per 2 KiB block
           const int64_t bi = (ocur >> MHL_BLK_SHIFT) + 2 * (int64_t)rcur;
@@ -699,7 +697,7 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
         }
       }
     }
-    if (!(a.ablate & 8)) mhl_add_range<G, 0, MHL_NU>(w, sub, cur, L);
+    mhl_add_range<G, 0, MHL_NU>(w, sub, cur, L);
     for (int k = sub + MHL_NU * G; k < cur.rs.nd; k += G) {
       MhlSlice t = cur;
 #pragma unroll
@@ -904,7 +902,6 @@ __global__ __launch_bounds__(WG, (mhl_waves_per_simd<WG, ST>())) void k_mhl_tile
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
-  if (a.ablate & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   mhl_emit<WG, true>(a, tile, L, s_scan);
 }
 
@@ -1639,8 +1636,6 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   ra.rec_cursor = rec_cursor;
   ra.cont = multi ? b->mhl_cont.as<uint32_t>() : nullptr;
   ra.max_h = b->misc.as<uint32_t>() + 14;                    // misc[14]
-  ra.ablate = 0;
-  if (const char *env = getenv("EPIHIP_MHL_ABLATE")) ra.ablate = atoi(env) >> 8;
 
   EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
   EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
@@ -1658,8 +1653,6 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.n = b->n; a.nbytes = b->nbytes; a.nblkrec = (int64_t)nblkrec;
   EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
 #endif
-  a.ablate = 0;
-  if (const char *env = getenv("EPIHIP_MHL_ABLATE")) a.ablate = atoi(env);
   a.tiles = b->tiles.as<Tile>();
   a.ctx_mask = ctx_mask; a.H = H;
   a.cursor = cursor;

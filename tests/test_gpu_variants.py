@@ -13,6 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("env", [
     {},                                                                  # defaults
+    {"EPIHIP_CX_ABLATE": "7", "EPIHIP_MHL_ABLATE": "4095", "EPIHIP_CX_DIAG": "1", "EPIHIP_CX_PACKED": "0"},   # round-1 timing switches: the
+                                                                         # product library no longer reads them (timing builds are a make target)
     {"EPIHIP_HEAVY_ROWS": "500"},                                        # pile-ups split over many workgroups (slabs in HBM)
     {"EPIHIP_HEAVY_ROWS": "100"},                                        # ... in chunks smaller than the u8 fold interval
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot

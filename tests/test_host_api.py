@@ -90,3 +90,12 @@ def test_write_report_tsv(tmp_path):
     import gzip
     ea.writeReport(rep, str(tmp_path / "r.tsv.gz"), gzip=True)
     assert gzip.open(tmp_path / "r.tsv.gz", "rt").read() == p.read_text()
+
+
+def test_no_timing_switches_in_the_product_library():
+    """Timing builds (phases skipped: wrong results by design) are a compile-time make target; the shipped library
+    must not contain the environment switches of round 1."""
+    from epialleler_amd import _lib
+    data = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"EPIHIP_CX_ABLATE", b"EPIHIP_MHL_ABLATE", b"EPIHIP_CX_DIAG"):
+        assert name not in data
