@@ -44,6 +44,10 @@ WORKLOADS = {
     "cfg4": dict(rows=50_000_000, read_len=300, kind="mhl", desc="50M PE150 templates, generateMhlReport defaults"),
     "cfg5": dict(rows=5_000_000, read_len=10000, kind="cx", threshold=False, report_context="CG",
                  desc="5M long-read (10 kb) templates, generateCytosineReport(threshold.reads=FALSE)"),
+    # the only throughput the reference publishes (vignettes/epialleleR.Rmd:172-176): BAM on disk -> CX report on disk
+    "file": dict(rows=1_000_000, read_len=300, kind="file",
+                 desc="name-sorted paired-end XG/XM BAM on disk (2 x 150 bp mates per template) -> preprocessBam -> "
+                      "generateCytosineReport defaults -> TSV report on disk"),
 }
 
 
@@ -65,6 +69,7 @@ def _parse():
     ap.add_argument("--selfcheck-rows", type=int, default=600_000, help="N>1: total rows of the reduced-size check")
     ap.add_argument("--no-extras", action="store_true", help="only the contract fields (no streamed / d2h / cfg2u / strong_cfg3)")
     ap.add_argument("--strong-steps", type=int, default=3)
+    ap.add_argument("--host-threads", type=int, default=0, help="file workload: BGZF inflate / packing / report writer threads (0 = min(cores, 16))")
     return ap.parse_args()
 
 
@@ -268,11 +273,82 @@ def streamed_and_d2h(cx, wl, res):
              "what": "the report table (6 int32 columns) copied to pinned host memory"})
 
 
+def file_workload(cx, args):
+    """BAM on disk -> report on disk, the reference's only published throughput (250-400 thousand reads/s on one
+    core of an i7-7700, HTSlib decode included).  One step = preprocessBam (host: BGZF inflate + template packing into
+    pinned SoA) + upload + generateCytosineReport defaults (fused kernel) + table to host + threaded TSV writer."""
+    import tempfile
+    ea, torch = cx.ea, cx.torch
+    wl = WORKLOADS["file"]
+    pairs = args.rows or wl["rows"]
+    nth = args.host_threads or max(1, min(os.cpu_count() or 1, 16))
+    tmp = tempfile.mkdtemp(prefix="epihip_bench_")
+    path, nrec = cx.synth.write_bam_paired(os.path.join(tmp, "in.bam"), pairs, threads=nth)
+    out_path = os.path.join(tmp, "report.tsv")
+    parts = []
+
+    def step():
+        t0 = time.perf_counter()
+        bam = ea.preprocessBam(path, nthreads=nth)
+        t1 = time.perf_counter()
+        bam.batch(cx.local)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rep = ea.generateCytosineReport(bam)
+        t3 = time.perf_counter()
+        ea.writeReport(rep, out_path, nthreads=nth)
+        t4 = time.perf_counter()
+        parts.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+        n, nrow = bam.n, rep.nrow
+        bam.close()
+        return n, nrow
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    parts.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_templ, nrow = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    avg = [sum(p[i] for p in parts) / len(parts) * 1e3 for i in range(4)]
+    out = {
+        "metric": "Mreads/s BAM file -> CX report file (generateCytosineReport; read = BAM record)",
+        "value": round(nrec * args.steps / dt / 1e6, 4), "unit": "Mreads/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "file: %s" % wl["desc"], "bam_records": nrec, "templates": n_templ, "bam_bytes": os.path.getsize(path),
+                   "report_rows": nrow, "report_bytes": os.path.getsize(out_path), "host_threads": nth,
+                   "ms": {"preprocessBam": round(avg[0], 2), "upload": round(avg[1], 2), "report_incl_table_to_host": round(avg[2], 2),
+                          "writeReport": round(avg[3], 2)},
+                   "templates_per_s_M": round(n_templ * args.steps / dt / 1e6, 4),
+                   "BAM_MB_per_s": round(os.path.getsize(path) * args.steps / dt / 1e6, 1)},
+        "published_reference": "250-400 thousand reads/s (30-50 MB/s of BAM), one core of an Intel Core i7-7700, HTSlib decode "
+                               "included (vignettes/epialleleR.Rmd:172-176); different hardware, so vs_baseline stays null",
+        "roofline": None, "cpu_baseline": None,
+    }
+    for f in (path, out_path):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = _parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _launch_ranks(args)
     cx = Ctx(args)
+    if args.workload == "file":
+        if cx.world > 1:
+            raise SystemExit("the file workload is a single-GPU measurement")
+        return file_workload(cx, args)
     np, torch = cx.np, cx.torch
     world, rank = cx.world, cx.rank
     wl = WORKLOADS[args.workload]

@@ -29,7 +29,7 @@ class SynthParams(C.Structure):
 class BamOptions(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("min_mapq", "min_baseq", "skip_duplicates", "skip_secondary", "skip_qcfail",
                                          "skip_supplementary", "trim5", "trim3", "paired", "nthreads", "min_prob",
-                                         "highest_prob")]
+                                         "highest_prob", "window_kib")]
 
 
 class Templates(C.Structure):
@@ -49,6 +49,11 @@ class MhlTable(C.Structure):
     _fields_ = [("nrow", C.c_int64)] + [(k, C.POINTER(C.c_int32)) for k in
                                         ("rname", "strand", "pos", "context", "coverage")] + \
                [("length", C.POINTER(C.c_double)), ("lmhl", C.POINTER(C.c_double))]
+
+
+class ReportColumn(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int32), ("data", C.c_void_p), ("levels", C.POINTER(C.c_char_p)),
+                ("nlevels", C.c_int32)]
 
 
 class PatternTable(C.Structure):
@@ -81,6 +86,7 @@ _SIGS = {
     "epi_mhl_report": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _CS, C.c_int, C.c_int, _F64, C.POINTER(MhlTable)]),
     "epi_preprocess_bam": (C.c_int, [_CS, C.POINTER(BamOptions), C.POINTER(Templates)]),
     "epi_templates_free": (None, [C.POINTER(Templates)]),
+    "epi_write_report": (C.c_int, [_CS, C.POINTER(ReportColumn), _I32, _I64, _I32, _I32]),
     "epi_engine_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "epi_engine_destroy": (None, [_VP]),
     "epi_engine_device": (C.c_int, [_VP]),

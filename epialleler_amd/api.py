@@ -175,7 +175,7 @@ def _as_bam(bam):
 
 def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, highest_prob=True,
                   skip_duplicates=False, skip_secondary=True, skip_qcfail=True, skip_supplementary=True,
-                  trim=0, nthreads=1, verbose=False):
+                  trim=0, nthreads=1, verbose=False, window_kib=0):
     """R/preprocessBam.R:197-237.  An already preprocessed object is returned untouched (:226-235);
     a path is decoded by the library's host-side producer (epi_preprocess_bam: zlib BGZF reader + the
     reference's template packer), which yields the sorted SoA batch directly."""
@@ -187,7 +187,7 @@ def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, h
     opt = _lib.BamOptions(int(min_mapq), int(min_baseq), int(bool(skip_duplicates)), int(bool(skip_secondary)),
                           int(bool(skip_qcfail)), int(bool(skip_supplementary)), int(trim2[0]), int(trim2[1]),
                           -1 if paired is None else int(bool(paired)), max(int(nthreads), 1), int(min_prob),
-                          int(bool(highest_prob)))
+                          int(bool(highest_prob)), int(window_kib))
     t = _lib.Templates()
     rc = lib.epi_preprocess_bam(os.path.expanduser(str(bam_file)).encode(), C.byref(opt), C.byref(t))
     if rc != _lib.EPI_OK:
@@ -415,22 +415,64 @@ def generateMhlReport(bam, report_file=None, haplotype_context=None, max_haploty
     return None
 
 
-def writeReport(report, report_file, gzip=False):
-    """R/internal.R:274-287 (.writeReport): TSV with header, factors written as their labels."""
-    cols = {}
+def writeReport(report, report_file, gzip=False, nthreads=None):
+    """R/internal.R:274-287 (.writeReport): TSV with header, factors written as their labels, NA / NaN as empty
+    fields -- data.table::fwrite's conventions.  Numeric and factor columns go through the library's threaded writer
+    (epi_write_report); a table with a text column (extractPatterns' hash) is written row by row here."""
+    import os
+    cols, keep = [], []
+    n = report.nrow
+    text_cols = False
     for k, v in report.items():
         a = v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
         lev = report.levels.get(k)
+        if a.dtype.kind == "f":
+            a = np.ascontiguousarray(a, np.float64)
+            cols.append((k, 1, a, None))
+        elif a.dtype.kind in "iub":
+            a = np.ascontiguousarray(a, np.int32)
+            cols.append((k, 2 if lev is not None else 0, a, lev))
+        else:
+            text_cols = True
+            cols.append((k, -1, a, lev))
+    if text_cols or not cols:
+        _write_report_py(cols, n, report_file, gzip)
+        return
+    lib = _lib.load()
+    arr = (_lib.ReportColumn * len(cols))()
+    for i, (k, kind, a, lev) in enumerate(cols):
+        arr[i].name = k.encode()
+        arr[i].kind = kind
+        arr[i].data = a.ctypes.data if a.size else None
         if lev is not None:
-            a = np.asarray(lev, dtype=object)[a - 1]
-        elif k == "rname":
-            a = a.astype(str)
-        cols[k] = a
-    names = list(cols)
+            lv = (C.c_char_p * len(lev))(*[str(x).encode("latin1") for x in lev])
+            keep.append(lv)
+            arr[i].levels = lv
+            arr[i].nlevels = len(lev)
+        keep.append(a)
+    if nthreads is None:
+        nthreads = min(os.cpu_count() or 1, 16)
+    rc = lib.epi_write_report(os.path.expanduser(str(report_file)).encode(), arr, len(cols), n, int(bool(gzip)), int(nthreads))
+    if rc != _lib.EPI_OK:
+        raise OSError(lib.epi_last_error().decode("utf-8", "replace"))
+
+
+def _write_report_py(cols, n, report_file, gzip):
     opener = (lambda p: _gzip.open(p, "wt")) if gzip else (lambda p: open(p, "w"))
+
+    def cell(kind, a, lev, i):
+        v = a[i]
+        if kind == 1:
+            return "" if np.isnan(v) else ("%.15g" % v)
+        if kind == -1:
+            return "" if v is None else str(v)
+        if int(v) == -2 ** 31:
+            return ""
+        if lev is not None:
+            return str(lev[int(v) - 1]) if 1 <= int(v) <= len(lev) else ""
+        return str(int(v))
+
     with opener(report_file) as f:
-        f.write("\t".join(names) + "\n")
-        n = report.nrow
-        fmt = [("%.15g" if cols[k].dtype.kind == "f" else "%s") for k in names]
+        f.write("\t".join(k for k, _, _, _ in cols) + "\n")
         for i in range(n):
-            f.write("\t".join(fm % cols[k][i] for fm, k in zip(fmt, names)) + "\n")
+            f.write("\t".join(cell(kind, a, lev, i) for _, kind, a, lev in cols) + "\n")

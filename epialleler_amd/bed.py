@@ -98,6 +98,8 @@ def generateBedReport(bam, bed, report_file=None, zero_based_bed=False, bed_type
     nbed = len(bed)
     slot = torch.where(match < 0, torch.full_like(match, nbed), match - 1).to(torch.int64)
     key = slot * 4 + (strand.to(torch.int64) - 1) * 2 + (pass_ != 0).to(torch.int64)
+    key = key[(strand >= 1) & (strand <= 2)]                # (strand 0: the reference's placeholder template of an empty paired-end
+                                                            # file, src/rcpp_read_bam.cpp:155 -- an NA strand, counted on neither)
     cnt = torch.bincount(key, minlength=(nbed + 1) * 4).reshape(nbed + 1, 2, 2).cpu().numpy().astype(np.float64)
     present = cnt.sum(axis=(1, 2)) > 0                      # regions with no read at all are NA after the merge
     rows = list(range(nbed)) + ([nbed] if present[nbed] else [])

@@ -17,9 +17,15 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <stdio.h>
+#include <limits.h>
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <new>
 #include <atomic>
 #include <numeric>
 #include <string>
@@ -37,60 +43,84 @@ struct Block { size_t cpos, clen; size_t upos, ulen; };   // compressed payload 
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-int read_file(const char *path, std::vector<uint8_t> &buf) {
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(EPI_ERR_ARG, "Unable to open BAM file for reading");   // src/rcpp_read_bam.cpp:34
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  buf.resize(sz > 0 ? (size_t)sz : 0);
-  size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
-  fclose(f);
-  if (got != buf.size()) return fail(EPI_ERR_ARG, "Unable to read BAM file");
+// The compressed file, memory-mapped (read into a buffer where mmap is not possible): nothing of it is copied.
+struct FileView {
+  const uint8_t *p = nullptr;
+  size_t n = 0;
+  bool mapped = false;
+  std::vector<uint8_t> own;
+  ~FileView() { if (mapped && p) munmap(const_cast<uint8_t *>(p), n); }
+};
+
+int open_file(const char *path, FileView &v) {
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return fail(EPI_ERR_ARG, "Unable to open BAM file for reading");   // src/rcpp_read_bam.cpp:34
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return fail(EPI_ERR_ARG, "Unable to read BAM file"); }
+  v.n = (size_t)st.st_size;
+  if (v.n == 0) { close(fd); return EPI_OK; }
+  void *m = mmap(nullptr, v.n, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (m != MAP_FAILED) { v.p = static_cast<const uint8_t *>(m); v.mapped = true; close(fd); return EPI_OK; }
+  v.own.resize(v.n);
+  size_t got = 0;
+  while (got < v.n) {
+    const ssize_t k = read(fd, v.own.data() + got, v.n - got);
+    if (k <= 0) break;
+    got += (size_t)k;
+  }
+  close(fd);
+  if (got != v.n) return fail(EPI_ERR_ARG, "Unable to read BAM file");
+  v.p = v.own.data();
   return EPI_OK;
 }
 
-// Locate the BGZF blocks (no inflation), then inflate them in parallel.
-int bgzf_inflate(const std::vector<uint8_t> &in, int nthreads, std::vector<uint8_t> &out) {
-  std::vector<Block> blocks;
-  size_t p = 0, total = 0;
-  while (p + 18 <= in.size()) {
-    const uint8_t *h = in.data() + p;
+// Locate the BGZF blocks (no inflation).
+int bgzf_scan(const uint8_t *in, size_t n, std::vector<Block> &blocks) {
+  size_t p = 0;
+  while (p + 18 <= n) {
+    const uint8_t *h = in + p;
     if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(EPI_ERR_ARG, "not a BGZF/BAM file");
     const unsigned xlen = rd16(h + 10);
-    size_t q = p + 12, xend = p + 12 + xlen;
+    size_t q = p + 12;
+    const size_t xend = p + 12 + xlen;
     int bsize = -1;
-    while (q + 4 <= xend && xend <= in.size()) {
-      const unsigned slen = rd16(in.data() + q + 2);
-      if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2) bsize = rd16(in.data() + q + 4);
+    while (q + 4 <= xend && xend <= n) {
+      const unsigned slen = rd16(in + q + 2);
+      if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = rd16(in + q + 4);
       q += 4 + slen;
     }
-    if (bsize < 0 || p + (size_t)bsize + 1 > in.size()) return fail(EPI_ERR_ARG, "truncated BGZF block");
+    if (bsize < 0 || p + (size_t)bsize + 1 > n) return fail(EPI_ERR_ARG, "truncated BGZF block");
     const size_t blen = (size_t)bsize + 1;
+    if (blen < (xend - p) + 8) return fail(EPI_ERR_ARG, "corrupt BGZF block");
     Block b;
     b.cpos = xend;
     b.clen = blen - (xend - p) - 8;
-    b.ulen = rd32(in.data() + p + blen - 4);
-    b.upos = total;
-    total += b.ulen;
+    b.ulen = rd32(in + p + blen - 4);
+    b.upos = 0;
+    if (b.ulen > 65536) return fail(EPI_ERR_ARG, "corrupt BGZF block");
     blocks.push_back(b);
     p += blen;
   }
-  out.resize(total);
-  std::atomic<size_t> next(0);
+  if (p != n) return fail(EPI_ERR_ARG, "truncated BGZF block");
+  return EPI_OK;
+}
+
+// Inflate blocks [b0, b1) to out + their upos, in parallel.
+int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size_t b0, size_t b1, uint8_t *out, int nthreads) {
+  std::atomic<size_t> next(b0);
   std::atomic<int> bad(0);
   auto work = [&]() {
     for (;;) {
       const size_t i = next.fetch_add(1);
-      if (i >= blocks.size()) break;
+      if (i >= b1) break;
       const Block &b = blocks[i];
       if (b.ulen == 0) continue;
       z_stream zs;
       memset(&zs, 0, sizeof(zs));
       if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
-      zs.next_in = const_cast<Bytef *>(in.data() + b.cpos);
+      zs.next_in = const_cast<Bytef *>(in + b.cpos);
       zs.avail_in = (uInt)b.clen;
-      zs.next_out = out.data() + b.upos;
+      zs.next_out = out + b.upos;
       zs.avail_out = (uInt)b.ulen;
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
@@ -98,7 +128,7 @@ int bgzf_inflate(const std::vector<uint8_t> &in, int nthreads, std::vector<uint8
     }
   };
   int nt = nthreads > 0 ? nthreads : 1;
-  if ((size_t)nt > blocks.size()) nt = blocks.empty() ? 1 : (int)blocks.size();
+  if ((size_t)nt > b1 - b0) nt = b1 > b0 ? (int)(b1 - b0) : 1;
   std::vector<std::thread> th;
   for (int t = 1; t < nt; t++) th.emplace_back(work);
   work();
@@ -315,9 +345,58 @@ void epi_templates_free(epi_templates *t) {
   memset(t, 0, sizeof(*t));
 }
 
+static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_templates *out);
+
 int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_templates *out) {
   if (!path || !out) return fail(EPI_ERR_ARG, "epi_preprocess_bam: NULL argument");
   memset(out, 0, sizeof(*out));
+  int rc;
+  try {                                                     // nothing may unwind through the C boundary
+    rc = preprocess_impl(path, opt_in, out);
+  } catch (const std::bad_alloc &) {
+    rc = fail(EPI_ERR_NOMEM, "epi_preprocess_bam: out of host memory");
+  } catch (...) {
+    rc = fail(EPI_ERR_ARG, "epi_preprocess_bam: unexpected failure while reading %s", path);
+  }
+  if (rc != EPI_OK) epi_templates_free(out);
+  return rc;
+}
+
+}  // extern "C"
+
+// One record of the inflated stream -> Rec, with the structural checks HTSlib's bam_read1 makes (sizes consistent
+// with block_size, NUL-terminated name); false: the record is not well-formed.
+static bool parse_record(const uint8_t *b, uint32_t bs, Rec *r) {
+  if (bs < 32) return false;
+  r->tid = (int32_t)rd32(b); r->pos = (int32_t)rd32(b + 4);
+  const uint32_t l_qname = b[8];
+  r->mapq = b[9];
+  r->n_cigar = rd16(b + 12); r->flag = rd16(b + 14);
+  r->l_seq = (int32_t)rd32(b + 16); r->mtid = (int32_t)rd32(b + 20); r->mpos = (int32_t)rd32(b + 24); r->isize = (int32_t)rd32(b + 28);
+  if (l_qname < 1 || r->l_seq < 0) return false;
+  const uint64_t need = 32ull + l_qname + 4ull * r->n_cigar + ((uint64_t)r->l_seq + 1) / 2 + (uint64_t)r->l_seq;
+  if (need > bs) return false;
+  r->qname = (const char *)b + 32;
+  if (b[32 + l_qname - 1] != 0) return false;
+  r->cigar = b + 32 + l_qname;
+  r->seq = r->cigar + 4 * (size_t)r->n_cigar;
+  r->qual = r->seq + ((size_t)r->l_seq + 1) / 2;
+  r->aux = r->qual + (size_t)r->l_seq;
+  r->end = b + bs;
+  return true;
+}
+
+// query bases the CIGAR consumes (M I S = X)
+static uint64_t cigar_qlen(const Rec &r) {
+  uint64_t q = 0;
+  for (uint32_t i = 0; i < r.n_cigar; i++) {
+    const uint32_t c = rd32(r.cigar + 4 * i), op = c & 0xF;
+    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q += c >> 4;
+  }
+  return q;
+}
+
+static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_templates *out) {
   epi_bam_options opt;
   if (opt_in) opt = *opt_in;
   else { memset(&opt, 0, sizeof(opt)); opt.skip_secondary = opt.skip_qcfail = opt.skip_supplementary = 1; opt.paired = -1; opt.nthreads = 1; opt.min_prob = -1; opt.highest_prob = 1; }
@@ -327,78 +406,40 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tm0 = tnow();
   auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[bam] %-10s %.3f s\n", what, t - tm0); tm0 = t; } };
-  std::vector<uint8_t> file, bam;
-  EPI_TRY(read_file(path, file));
-  EPI_TRY(bgzf_inflate(file, opt.nthreads, bam));
-  file.clear(); file.shrink_to_fit();
-  lap("inflate");
-  if (bam.size() < 12 || memcmp(bam.data(), "BAM\1", 4) != 0) return fail(EPI_ERR_ARG, "Unable to read BAM header");
-  size_t p = 8 + (size_t)rd32(bam.data() + 4);
-  if (p + 4 > bam.size()) return fail(EPI_ERR_ARG, "Unable to read BAM header");
-  const uint32_t n_ref = rd32(bam.data() + p);
-  p += 4;
+  FileView file;
+  EPI_TRY(open_file(path, file));
+  std::vector<Block> blocks;
+  EPI_TRY(bgzf_scan(file.p, file.n, blocks));
+
+  // The file is processed in windows of inflated data (the reference streams records through HTSlib): inflate a run
+  // of BGZF blocks, index the complete records, pack the complete templates, carry the rest (a record cut by the
+  // window, or the records of a template whose mate is still to come) over to the next window.
+  const size_t window = opt.window_kib > 0 ? (size_t)opt.window_kib * 1024 : (size_t)256 << 20;
+  std::vector<uint8_t> buf;
+  size_t carry = 0, bi = 0, hdr_end = 0;
+  bool header_done = false, checked = false, paired = false, tMM = false;
   std::vector<std::string> names;
-  for (uint32_t i = 0; i < n_ref; i++) {
-    if (p + 4 > bam.size()) return fail(EPI_ERR_ARG, "Unable to read BAM header");
-    const uint32_t l = rd32(bam.data() + p);
-    if (p + 4 + l + 4 > bam.size()) return fail(EPI_ERR_ARG, "Unable to read BAM header");
-    names.emplace_back((const char *)bam.data() + p + 4);
-    p += 4 + l + 4;
-  }
-  // record index
   std::vector<Rec> recs;
-  while (p + 4 <= bam.size()) {
-    const uint32_t bs = rd32(bam.data() + p);
-    if (bs < 32 || p + 4 + bs > bam.size()) return fail(EPI_ERR_ARG, "truncated BAM record");
-    const uint8_t *b = bam.data() + p + 4;
-    Rec r;
-    r.tid = (int32_t)rd32(b); r.pos = (int32_t)rd32(b + 4);
-    const uint32_t l_qname = b[8];
-    r.mapq = b[9];
-    r.n_cigar = rd16(b + 12); r.flag = rd16(b + 14);
-    r.l_seq = (int32_t)rd32(b + 16); r.mtid = (int32_t)rd32(b + 20); r.mpos = (int32_t)rd32(b + 24); r.isize = (int32_t)rd32(b + 28);
-    r.qname = (const char *)b + 32;
-    r.cigar = b + 32 + l_qname;
-    r.seq = r.cigar + 4 * (size_t)r.n_cigar;
-    r.qual = r.seq + ((size_t)r.l_seq + 1) / 2;
-    r.aux = r.qual + (size_t)r.l_seq;
-    r.end = b + bs;
-    if (r.aux > r.end) return fail(EPI_ERR_ARG, "corrupt BAM record");
-    recs.push_back(r);
-    p += 4 + (size_t)bs;
-  }
-
-  lap("index");
-  // ---- .checkBam over the first 1024 records (src/rcpp_check_bam.cpp:40-50, R/internal.R:82-120) ----
-  size_t nrecs = 0, npaired = 0, ntempls = 0;
-  bool tXG = false, tXM = false, tYD = false, tZS = false, tMM = false;
-  const char *prevq = nullptr;
-  for (const Rec &r : recs) {
-    if (nrecs >= 1024) break;
-    nrecs++;
-    if (r.flag & 0x2) npaired++;
-    tXG |= has_tag(r, 'X', 'G'); tXM |= has_tag(r, 'X', 'M'); tYD |= has_tag(r, 'Y', 'D'); tZS |= has_tag(r, 'Z', 'S');
-    tMM |= has_tag(r, 'M', 'M') || has_tag(r, 'M', 'm');
-    if (prevq && strcmp(prevq, r.qname) == 0) ntempls++;
-    prevq = r.qname;
-  }
-  const bool paired = npaired * 2 > nrecs;
-  const bool sorted = ntempls > 0 && (ntempls >= nrecs / 2 || ntempls >= npaired / 2);
-  if (nrecs == 0) return fail(EPI_ERR_ARG, "Empty file provided! Exiting");
-  if (!tXG && tYD) return fail(EPI_ERR_ARG, "No XG tags found (though YD tags are there)! BWA-meth alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
-  if (!tXG && tZS) return fail(EPI_ERR_ARG, "No XG tags found (though ZS tags are there)! BSMAP alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
-  if (!tXM && tXG) return fail(EPI_ERR_ARG, "No XM tags found! Was methylation called successfully? If not, make methylation calls using epialleleR::callMethylation. Exiting");
-  if (!tMM && !(tXG && tXM)) return fail(EPI_ERR_ARG, "No known methylation tags found! Exiting");
-  if (paired && !sorted) return fail(EPI_ERR_ARG, "BAM file seems to be paired-end but not sorted by name! Please sort using 'samtools sort -n -o out.bam in.bam'. Exiting");
-  if (opt.paired >= 0 && (opt.paired != 0) != paired) return fail(EPI_ERR_ARG, "Expected endness is different from detected! Exiting");
-
-  // ---- .readBam: skip flags (R/internal.R:173-177) and the packers ----
+  size_t nrecs_total = 0;
   uint16_t skip_flags = 4;
   if (opt.skip_secondary) skip_flags |= 256;
   if (opt.skip_qcfail) skip_flags |= 512;
   if (opt.skip_duplicates) skip_flags |= 1024;
   if (opt.skip_supplementary) skip_flags |= 2048;
   const int trim5 = opt.trim5, trim3 = opt.trim3;
+  Packed P;
+  P.off.push_back(0);
+
+  // ---- .readBam: skip flags (R/internal.R:173-177, above) and the packers ----
+  // a record that enters a template must be self-consistent: the CIGAR consumes exactly the stored bases, XM covers
+  // them, the reference id exists (HTSlib rejects such records while reading; without the checks they index past
+  // the record)
+  auto use_record = [&](const Rec &r, const char *xm) -> int {
+    if (r.tid < 0 || (size_t)r.tid >= names.size()) return fail(EPI_ERR_ARG, "corrupt BAM record %s: reference id out of range", r.qname);
+    if (cigar_qlen(r) != (uint64_t)r.l_seq) return fail(EPI_ERR_ARG, "corrupt BAM record %s: CIGAR does not match the sequence length", r.qname);
+    if (xm && strlen(xm) < (size_t)r.l_seq) return fail(EPI_ERR_ARG, "corrupt BAM record %s: XM tag shorter than the sequence", r.qname);
+    return EPI_OK;
+  };
   // Each packer turns records [r_lo, r_hi) into templates appended to P; ranges are packed by several threads and
   // concatenated in order (a paired-end range never starts inside a template).
   auto pack_mm = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
@@ -410,6 +451,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
     for (size_t ri = r_lo; ri < r_hi; ri++) {
       const Rec &r = recs[ri];
       if ((r.flag & skip_flags) || (int)r.mapq < opt.min_mapq) continue;                        // :423-424
+      EPI_TRY(use_record(r, nullptr));
       const int record_strand = (r.flag & 16) ? 1 : 0;                                          // :426
       const int32_t qw = r.l_seq < 0 ? -r.l_seq : r.l_seq;                                      // :436
       uint32_t width = 0;                                                                       // bam_cigar2rlen, :437
@@ -499,16 +541,19 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       bool pg, pm;
       const char *xg = aux_z(r, 'X', 'G', &pg), *xm = aux_z(r, 'X', 'M', &pm);
       if (!pg || !pm || !xg || !xm) continue;                                                   // :80-82
+      EPI_TRY(use_record(r, xm));
       if (!tname || strcmp(tname, r.qname) != 0) {                                              // :85
         if (t_strand != 0) push_template();
         tname = r.qname;
         t_rname = r.tid;
         t_start = r.pos < r.mpos ? r.pos : r.mpos;                                              // :92-93
+        if (r.isize == INT32_MIN) return fail(EPI_ERR_ARG, "corrupt BAM record %s: template length", r.qname);
         t_width = r.isize < 0 ? -r.isize : r.isize;                                             // :94
         t_strand = 2 - (xg[0] == 'C' ? 1 : 0);                                                  // :95
         if ((size_t)t_width > tq.size()) { tq.resize((size_t)t_width, q0); ts.resize((size_t)t_width, 0xFB); }
       }
       uint32_t dest_end = 0;
+      if (r.pos < t_start) return fail(EPI_ERR_ARG, "corrupt BAM record %s: starts before its template", r.qname);
       const uint32_t dest0 = (uint32_t)(r.pos - t_start);                                       // :118
       EPI_TRY(apply_cigar(r, dest0, [&](uint32_t qpos, uint32_t dpos, uint32_t len) {
         if ((size_t)dpos + len > tq.size()) { tq.resize((size_t)dpos + len, q0); ts.resize((size_t)dpos + len, 0xFB); }
@@ -519,7 +564,9 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
           }
         }
       }, &dest_end));
+      if (dest_end > 0x7FFFFFFFu) return fail(EPI_ERR_ARG, "corrupt BAM record %s: template too wide", r.qname);
       if (t_width < (int)dest_end) t_width = (int)dest_end;                                     // :151
+      if ((size_t)t_width > tq.size()) { tq.resize((size_t)t_width, q0); ts.resize((size_t)t_width, 0xFB); }   // (a CIGAR ending in D / N)
     }
     if (t_strand != 0) push_template();                                                         // :155 (see below for "none")
     return EPI_OK;
@@ -532,6 +579,7 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       bool pg, pm;
       const char *xg = aux_z(r, 'X', 'G', &pg), *xm = aux_z(r, 'X', 'M', &pm);
       if (!pg || !pm || !xg || !xm) continue;
+      EPI_TRY(use_record(r, xm));
       uint32_t width = 0;                                                                       // bam_cigar2rlen, :255
       for (uint32_t i = 0; i < r.n_cigar; i++) {
         const uint32_t c = rd32(r.cigar + 4 * i), op = c & 0xF;
@@ -554,25 +602,30 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
     return EPI_OK;
   };
 
-  Packed P;
-  P.off.push_back(0);
-  {
+  // packs records [0, r_end) of the current window with K threads and appends the templates to P
+  auto pack_window = [&](size_t r_end) -> int {
     size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
-    if (recs.size() < 1024) K = 1;
+    if (r_end < 1024) K = 1;
     std::vector<size_t> cut(K + 1);
     for (size_t k = 0; k <= K; k++) {
-      size_t c = recs.size() * k / K;
+      size_t c = r_end * k / K;
       if (!tMM && paired)                                   // a template's records are neighbours with one QNAME
-        while (c > 0 && c < recs.size() && strcmp(recs[c].qname, recs[c - 1].qname) == 0) c++;
+        while (c > 0 && c < r_end && strcmp(recs[c].qname, recs[c - 1].qname) == 0) c++;
       cut[k] = c;
     }
     std::vector<Packed> part(K);
     std::vector<int> rcs(K, EPI_OK);
     std::vector<std::string> msgs(K);
     auto run = [&](size_t k) {
-      part[k].off.push_back(0);
-      rcs[k] = tMM ? pack_mm(cut[k], cut[k + 1], part[k]) : paired ? pack_pe(cut[k], cut[k + 1], part[k]) : pack_se(cut[k], cut[k + 1], part[k]);
-      if (rcs[k] != EPI_OK) msgs[k] = epi_last_error();     // the message is thread-local
+      try {
+        part[k].off.push_back(0);
+        rcs[k] = tMM ? pack_mm(cut[k], cut[k + 1], part[k]) : paired ? pack_pe(cut[k], cut[k + 1], part[k]) : pack_se(cut[k], cut[k + 1], part[k]);
+        if (rcs[k] != EPI_OK) msgs[k] = epi_last_error();   // the message is thread-local
+      } catch (const std::bad_alloc &) {
+        rcs[k] = EPI_ERR_NOMEM; msgs[k] = "epi_preprocess_bam: out of host memory";
+      } catch (...) {
+        rcs[k] = EPI_ERR_ARG; msgs[k] = "epi_preprocess_bam: unexpected failure while packing templates";
+      }
     };
     std::vector<std::thread> th;
     for (size_t k = 1; k < K; k++) th.emplace_back(run, k);
@@ -589,10 +642,107 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
       for (size_t i = 1; i < q.off.size(); i++) P.off.push_back(q.off[i] + shift);
       P.bytes.insert(P.bytes.end(), q.bytes.begin(), q.bytes.end());
     }
-    if (!tMM && paired && P.rname.empty()) {                // the reference pushes its (never opened) template all the same, :155
-      P.rname.push_back(1); P.strand.push_back(0); P.start.push_back(trim5 + 1); P.off.push_back(0);
+    return EPI_OK;
+  };
+
+  // ---- the windows ----
+  for (bool final = blocks.empty(); ;) {
+    size_t b1 = bi, add = 0;
+    while (b1 < blocks.size() && (b1 == bi || add + blocks[b1].ulen <= window)) { blocks[b1].upos = carry + add; add += blocks[b1].ulen; b1++; }
+    final = b1 == blocks.size();
+    buf.resize(carry + add);
+    EPI_TRY(bgzf_inflate_range(file.p, blocks, bi, b1, buf.data(), opt.nthreads));
+    bi = b1;
+    size_t p = hdr_end;
+    if (!header_done) {                                      // BAM header: magic, text, reference names
+      bool complete = false;
+      do {
+        if (buf.size() < 12) break;
+        if (memcmp(buf.data(), "BAM\1", 4) != 0) return fail(EPI_ERR_ARG, "Unable to read BAM header");
+        size_t q = 8 + (size_t)rd32(buf.data() + 4);
+        if (q + 4 > buf.size()) break;
+        const uint32_t n_ref = rd32(buf.data() + q);
+        q += 4;
+        names.clear();
+        bool ok = true;
+        for (uint32_t i = 0; i < n_ref && ok; i++) {
+          if (q + 4 > buf.size()) { ok = false; break; }
+          const uint32_t l = rd32(buf.data() + q);
+          if (q + 4 + (size_t)l + 4 > buf.size()) { ok = false; break; }
+          if (l == 0 || buf[q + 4 + l - 1] != 0) return fail(EPI_ERR_ARG, "Unable to read BAM header");
+          names.emplace_back((const char *)buf.data() + q + 4);
+          q += 4 + (size_t)l + 4;
+        }
+        if (!ok) break;
+        hdr_end = q;
+        complete = true;
+      } while (0);
+      if (!complete) {
+        if (final) return fail(EPI_ERR_ARG, "Unable to read BAM header");
+        carry = buf.size();                                  // the header is longer than a window: read on
+        continue;
+      }
+      header_done = true;
+      p = hdr_end;
     }
+    // index of the complete records of the window
+    recs.clear();
+    while (p + 4 <= buf.size()) {
+      const uint32_t bs = rd32(buf.data() + p);
+      if (p + 4 + (size_t)bs > buf.size()) break;            // cut by the window (or by the end of the file)
+      Rec r;
+      if (!parse_record(buf.data() + p + 4, bs, &r)) return fail(EPI_ERR_ARG, "corrupt BAM record");
+      recs.push_back(r);
+      p += 4 + (size_t)bs;
+    }
+    if (final && p != buf.size()) return fail(EPI_ERR_ARG, "truncated BAM record");
+    if (!checked) {
+      if (recs.size() < 1024 && !final) { carry = buf.size(); continue; }   // .checkBam looks at the first 1024 records
+      lap("index");
+      // ---- .checkBam over the first 1024 records (src/rcpp_check_bam.cpp:40-50, R/internal.R:82-120) ----
+      size_t nrecs = 0, npaired = 0, ntempls = 0;
+      bool tXG = false, tXM = false, tYD = false, tZS = false;
+      const char *prevq = nullptr;
+      for (const Rec &r : recs) {
+        if (nrecs >= 1024) break;
+        nrecs++;
+        if (r.flag & 0x2) npaired++;
+        tXG |= has_tag(r, 'X', 'G'); tXM |= has_tag(r, 'X', 'M'); tYD |= has_tag(r, 'Y', 'D'); tZS |= has_tag(r, 'Z', 'S');
+        tMM |= has_tag(r, 'M', 'M') || has_tag(r, 'M', 'm');
+        if (prevq && strcmp(prevq, r.qname) == 0) ntempls++;
+        prevq = r.qname;
+      }
+      paired = npaired * 2 > nrecs;
+      const bool sorted = ntempls > 0 && (ntempls >= nrecs / 2 || ntempls >= npaired / 2);
+      if (nrecs == 0) return fail(EPI_ERR_ARG, "Empty file provided! Exiting");
+      if (!tXG && tYD) return fail(EPI_ERR_ARG, "No XG tags found (though YD tags are there)! BWA-meth alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
+      if (!tXG && tZS) return fail(EPI_ERR_ARG, "No XG tags found (though ZS tags are there)! BSMAP alignment? If so, make methylation calls using epialleleR::callMethylation. Exiting");
+      if (!tXM && tXG) return fail(EPI_ERR_ARG, "No XM tags found! Was methylation called successfully? If not, make methylation calls using epialleleR::callMethylation. Exiting");
+      if (!tMM && !(tXG && tXM)) return fail(EPI_ERR_ARG, "No known methylation tags found! Exiting");
+      if (paired && !sorted) return fail(EPI_ERR_ARG, "BAM file seems to be paired-end but not sorted by name! Please sort using 'samtools sort -n -o out.bam in.bam'. Exiting");
+      if (opt.paired >= 0 && (opt.paired != 0) != paired) return fail(EPI_ERR_ARG, "Expected endness is different from detected! Exiting");
+      checked = true;
+    }
+    // paired-end: the records of the window's last QNAME wait for the next window (their mate may be in it)
+    size_t r_end = recs.size();
+    if (!final && paired && !tMM && r_end > 0) {
+      const char *lastq = recs[r_end - 1].qname;
+      while (r_end > 0 && strcmp(recs[r_end - 1].qname, lastq) == 0) r_end--;
+      if (r_end == 0) { carry = buf.size(); continue; }      // one template fills the window: read on
+    }
+    EPI_TRY(pack_window(r_end));
+    nrecs_total += r_end;
+    const size_t keep_from = r_end < recs.size() ? (size_t)(reinterpret_cast<const uint8_t *>(recs[r_end].qname) - 36 - buf.data()) : p;
+    carry = buf.size() - keep_from;
+    if (carry) memmove(buf.data(), buf.data() + keep_from, carry);
+    hdr_end = 0;                                             // (the header is gone from the buffer)
+    recs.clear();
+    if (final) break;
   }
+  if (!tMM && paired && P.rname.empty()) {                  // the reference pushes its (never opened) template all the same, :155
+    P.rname.push_back(1); P.strand.push_back(0); P.start.push_back(trim5 + 1); P.off.push_back(0);
+  }
+  { std::vector<uint8_t>().swap(buf); }
 
   lap("pack");
   // ---- templid := 0..N-1 ; setorder(rname, start) -- stable (R/internal.R:193-195) ----
@@ -633,11 +783,9 @@ int epi_preprocess_bam(const char *path, const epi_bam_options *opt_in, epi_temp
   out->n = (int64_t)n;
   out->nbytes = w;
   out->xm_capacity = (int64_t)cap;
-  out->nrecs = (int64_t)recs.size();
+  out->nrecs = (int64_t)nrecs_total;
   out->paired = paired ? 1 : 0;
   out->n_targets = (int32_t)names.size();
   for (size_t i = 0; i < names.size(); i++) out->target_names[i] = strdup(names[i].c_str());
   return EPI_OK;
 }
-
-}  // extern "C"

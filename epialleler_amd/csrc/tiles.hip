@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
     const int32_t s0 = start[x];
     if (l < 0 || (int64_t)s0 + l > 0x7FFFFFFFLL) bad_len = 1; else len = (int)l;
     const int32_t sd = strand[x];
-    if (sd != 1 && sd != 2) bad_strand = 1;
+    if (sd != 1 && sd != 2 && l != 0) bad_strand = 1;       // (an empty row may carry strand 0: the placeholder template the
+                                                            // reference pushes for a paired-end file without a usable pair,
+                                                            // src/rcpp_read_bam.cpp:155; it has no bases to count)
     if (x > 0) {
       const int32_t r0 = rname[x - 1], r1 = rname[x];
       if (r1 < r0 || (r1 == r0 && s0 < start[x - 1])) unsorted = 1;

@@ -116,3 +116,76 @@ def generate_device_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, r
                                           C.c_void_p(xm.data_ptr()), C.c_void_p(strand.data_ptr()), _stream(device)))
     levels = tuple("chrS%d" % (i + 1) for i in range(n_chr))
     return ProcessedBam.from_device(xm, nbytes, off, rname.contiguous(), strand, start.contiguous(), levels)
+
+
+# ---- a name-sorted paired-end XG/XM BAM on disk (file-to-file bench workload; numpy + zlib only) --------------------
+def write_bam_paired(path, n_pairs, n_chr=4, read_len=150, depth=30, seed=42, threads=8, level=1):
+    """2 * n_pairs records (mates 99/147 or 83/163, abutting: template = 2 * read_len bases), XM drawn with the
+    context frequencies of the synthetic model, XG = CT / GA per template.  All records have the same size, so the
+    whole uncompressed stream is one structured numpy array; BGZF blocks are deflated by a thread pool."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    L = int(read_len)
+    rng = np.random.default_rng(seed)
+    rec = np.dtype([("bs", "<i4"), ("refid", "<i4"), ("pos", "<i4"), ("lrn", "u1"), ("mapq", "u1"), ("bin", "<u2"),
+                    ("ncig", "<u2"), ("flag", "<u2"), ("lseq", "<i4"), ("mrefid", "<i4"), ("mpos", "<i4"), ("tlen", "<i4"),
+                    ("qname", "u1", 10), ("cigar", "<u4"), ("seq", "u1", (L + 1) // 2), ("qual", "u1", L),
+                    ("xmtag", "u1", 3), ("xm", "u1", L), ("xmnul", "u1"), ("xg", "u1", 6)])
+    n = 2 * int(n_pairs)
+    a = np.zeros(n, rec)
+    chr_len = max(int(n_pairs) * 2 * L // (depth * n_chr), 2 * L + 1)
+    tid = rng.integers(0, n_chr, n_pairs).astype(np.int32)
+    p1 = rng.integers(0, chr_len - 2 * L, n_pairs).astype(np.int32)            # 0-based leftmost position of the template
+    fwd = rng.random(n_pairs) < 0.5
+    a["bs"] = rec.itemsize - 4
+    a["refid"] = np.repeat(tid, 2)
+    a["mrefid"] = a["refid"]
+    a["pos"][0::2] = p1
+    a["pos"][1::2] = p1 + L
+    a["mpos"][0::2] = p1 + L
+    a["mpos"][1::2] = p1
+    a["tlen"][0::2] = 2 * L
+    a["tlen"][1::2] = -2 * L
+    a["lrn"] = 10
+    a["mapq"] = 60
+    a["bin"] = 4680
+    a["ncig"] = 1
+    a["flag"][0::2] = np.where(fwd, 99, 83)
+    a["flag"][1::2] = np.where(fwd, 147, 163)
+    a["lseq"] = L
+    a["cigar"] = (L << 4) | 0
+    idx = np.repeat(np.arange(n_pairs, dtype=np.int64), 2)
+    q = a["qname"]
+    q[:, 0] = ord("q")
+    for d in range(8):
+        q[:, 8 - d] = 48 + (idx // 10 ** d) % 10
+    q[:, 9] = 0
+    a["seq"] = np.asarray([0x11, 0x22, 0x44, 0x88, 0x12, 0x48, 0x21, 0x84], np.uint8)[rng.integers(0, 8, (n, (L + 1) // 2))]
+    a["qual"] = 37
+    a["xmtag"] = np.frombuffer(b"XMZ", np.uint8)
+    letters = np.frombuffer(b".hxzuHXZ", np.uint8)
+    a["xm"] = letters[rng.choice(8, size=(n, L), p=[0.76, 0.128, 0.057, 0.030, 0.01, 0.007, 0.003, 0.005])]
+    a["xg"][0::2] = np.where(fwd[:, None], np.frombuffer(b"XGZCT\0", np.uint8), np.frombuffer(b"XGZGA\0", np.uint8))
+    a["xg"][1::2] = a["xg"][0::2]
+    text = ("@HD\tVN:1.0\tSO:queryname\n" + "".join("@SQ\tSN:chrB%d\tLN:%d\n" % (i + 1, chr_len) for i in range(n_chr))).encode()
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", n_chr)
+    for i in range(n_chr):
+        nm = ("chrB%d" % (i + 1)).encode() + b"\0"
+        head += struct.pack("<i", len(nm)) + nm + struct.pack("<i", chr_len)
+    raw = memoryview(a).cast("B")
+
+    def block(data):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    step = 65280 // rec.itemsize * rec.itemsize                              # whole records per block
+    with open(path, "wb") as f, ThreadPoolExecutor(max(1, int(threads))) as pool:
+        f.write(block(head))
+        for out in pool.map(lambda o: block(bytes(raw[o:o + step])), range(0, len(raw), step)):
+            f.write(out)
+        f.write(block(b""))
+    return path, n

@@ -108,6 +108,7 @@ typedef struct {
   /* long-read (MM/ML) alignments only, rcpp_read_bam_mm_single (src/rcpp_read_bam.cpp:364-372): */
   int32_t min_prob;    /* minimum ML probability of a 5mC call (R default -1)                            */
   int32_t highest_prob;/* the 5mC probability must be the highest of all modifications at the base (TRUE) */
+  int32_t window_kib;  /* inflated KiB processed per pass (0 = 262144): bounds the host memory next to the output */
 } epi_bam_options;
 
 typedef struct {       /* library-owned; release with epi_templates_free */
@@ -122,6 +123,23 @@ typedef struct {       /* library-owned; release with epi_templates_free */
 
 int epi_preprocess_bam(const char *path, const epi_bam_options *opt /* NULL = R defaults */, epi_templates *out);
 void epi_templates_free(epi_templates *t);
+
+/* ---- report writer (.writeReport, R/internal.R:274-287) -------------------
+ * The table as a tab-separated file with a header line, what data.table::fwrite(report, quote=FALSE, sep="\t",
+ * col.names=TRUE, compress=if (gzip) "gzip" else "none") writes: integers in decimal, factor columns as their
+ * labels, doubles with up to 15 significant digits; NA_integer_ (INT32_MIN), factor codes outside 1..nlevels and
+ * NaN are empty fields (na = "").  Rows are formatted by `nthreads` host threads; with gzip != 0 the file is a
+ * multi-member gzip file. */
+enum { EPI_COL_I32 = 0, EPI_COL_F64 = 1, EPI_COL_FACTOR = 2 };
+typedef struct {
+  const char *name;            /* header field */
+  int32_t kind;                /* EPI_COL_* */
+  const void *data;            /* int32_t[nrow] (I32, FACTOR: 1-based codes) or double[nrow] (F64) */
+  const char *const *levels;   /* FACTOR: labels */
+  int32_t nlevels;
+} epi_report_column;
+int epi_write_report(const char *path, const epi_report_column *cols, int32_t ncol, int64_t nrow, int32_t gzip,
+                     int32_t nthreads);
 
 /* ---- resident API -------------------------------------------------------- */
 

@@ -21,7 +21,7 @@ import ctypes as C
 from epialleler_amd import _lib
 lib = _lib.load()
 for th in (1, 1, 2, 4, 8, 16):
-    opt = _lib.BamOptions(0, 0, 0, 1, 1, 1, 0, 0, -1, th, -1, 1)
+    opt = _lib.BamOptions(0, 0, 0, 1, 1, 1, 0, 0, -1, th, -1, 1, 0)
     t = _lib.Templates()
     t0 = time.time(); rc = lib.epi_preprocess_bam(p.encode(), C.byref(opt), C.byref(t)); t1 = time.time()
     print("C call nthreads=%d: rc %d, %d templates, %.3f s -> %.2f M reads/s" % (th, rc, t.n, t1 - t0, t.n / (t1 - t0) / 1e6), flush=True)

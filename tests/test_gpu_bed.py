@@ -75,3 +75,37 @@ def test_bed_ecdf():
     np.testing.assert_allclose(vals, [0.916666666667, 1, 0.885245901639, 1, 0.946236559140, 1, 0.892857142857, 1,
                                       0.868131868132, 1], atol=1e-8)                                   # :21-26
     assert list(e.keys())[-1] is None
+
+
+def test_bed_report_file_has_fwrite_na_fields(tmp_path):
+    """generateBedReport(report.file=...): the file data.table::fwrite would write -- NA fields empty (the last row
+    collects the reads that match no amplicon: NA seqnames/start/end/width/strand/name), counts without a fraction."""
+    import epialleler_amd as ea
+    amp_bam, amp_bed = os.path.join(BAM, "amplicon010meth.bam"), os.path.join(BAM, "amplicon.bed")
+    out = tmp_path / "amp.tsv"
+    assert ea.generateAmpliconReport(amp_bam, amp_bed, report_file=str(out)) is None
+    rep = ea.generateAmpliconReport(amp_bam, amp_bed)
+    lines = out.read_text().rstrip("\n").split("\n")
+    assert lines[0].split("\t") == list(rep.keys()) and len(lines) == 1 + rep.nrow
+    last = lines[-1].split("\t")
+    assert last[:6] == [""] * 6 and last[6] == "%d" % rep["nreads+"][-1] and last[7] == "%d" % rep["nreads-"][-1]
+    assert float(last[8]) == pytest.approx(rep["VEF"][-1], rel=1e-14)
+    first = lines[1].split("\t")
+    assert first[0] == rep["seqnames"][0] and first[1] == "%d" % rep["start"][0] and first[4] == "*" and "nan" not in out.read_text().lower()
+    nothr = tmp_path / "nothr.tsv"
+    ea.generateAmpliconReport(amp_bam, amp_bed, threshold_reads=False, report_file=str(nothr))
+    assert all(l.split("\t")[8] == "" for l in nothr.read_text().rstrip("\n").split("\n")[1:])      # VEF is NA without thresholding
+
+
+def test_placeholder_template_is_harmless():
+    """A paired-end file without a usable pair gives the reference's placeholder template (strand code 0, no bases,
+    src/rcpp_read_bam.cpp:155): reports are empty tables, the BED report counts it on neither strand."""
+    import epialleler_amd as ea
+    t = {"xm": np.zeros(0, np.uint8), "off": np.zeros(2, np.int64), "rname": np.ones(1, np.int32),
+         "strand": np.zeros(1, np.int32), "start": np.ones(1, np.int32)}
+    bam = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"], levels=["chr17"])
+    assert ea.generateCytosineReport(bam).nrow == 0 and ea.generateMhlReport(bam).nrow == 0
+    bed = ea.Bed(["chr17"], [1], [100])
+    rep = ea.generateBedReport(bam, bed, bed_type="capture")
+    assert rep.nrow == 1 and np.isnan(rep["nreads+"][0]) and np.isnan(rep["nreads-"][0])
+    bam.close()

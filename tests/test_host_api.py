@@ -92,6 +92,42 @@ def test_write_report_tsv(tmp_path):
     assert gzip.open(tmp_path / "r.tsv.gz", "rt").read() == p.read_text()
 
 
+def test_write_report_na_and_many_rows(tmp_path):
+    """fwrite conventions: NA_integer_, factor codes outside the levels and NaN are empty fields (na = ""); many rows
+    (several formatting chunks, several threads) come out in order; gzip output is a valid multi-member file."""
+    import gzip
+    import epialleler_amd as ea
+    n = 200_003
+    rng = np.random.default_rng(5)
+    cov = rng.integers(0, 50, n).astype(np.int32)
+    cov[7] = -2 ** 31
+    lm = rng.random(n)
+    lm[3] = np.nan
+    lm[4] = 0.5
+    lm[5] = 2.0
+    lm[6] = np.inf
+    ctx = rng.choice(np.asarray([2, 6, 7], np.int32), n)
+    ctx[9] = 5
+    rep = ea.Report({"rname": np.ones(n, np.int32), "strand": (1 + (np.arange(n) & 1)).astype(np.int32),
+                     "pos": np.arange(n, dtype=np.int32) - 5, "context": ctx, "coverage": cov, "lmhl": lm}, ["chrA"])
+    p = tmp_path / "big.tsv"
+    ea.writeReport(rep, str(p), nthreads=5)
+    lines = p.read_text().split("\n")
+    assert lines[0] == "rname\tstrand\tpos\tcontext\tcoverage\tlmhl" and len(lines) == n + 2 and lines[-1] == ""
+    want = lambda i: "\t".join(["chrA", "+-"[i & 1], str(i - 5), {2: "CHH", 5: "NA5", 6: "CHG", 7: "CG"}[int(ctx[i])],
+                                 "" if cov[i] == -2 ** 31 else str(int(cov[i])), "" if np.isnan(lm[i]) else ("Inf" if np.isinf(lm[i]) else "%.15g" % lm[i])])
+    for i in list(range(12)) + [65535, 65536, 65537, 131071, 131072, n - 1]:
+        assert lines[1 + i] == want(i), i
+    assert lines[1 + 3].endswith("\t") and lines[1 + 4].endswith("\t0.5") and lines[1 + 5].endswith("\t2")
+    ea.writeReport(rep, str(tmp_path / "big.tsv.gz"), gzip=True, nthreads=3)
+    assert gzip.open(tmp_path / "big.tsv.gz", "rt").read() == p.read_text()
+    # a table with a text column takes the row-by-row path with the same conventions
+    rep2 = ea.Report({"strand": np.asarray([1, 2], np.int32), "beta": np.asarray([np.nan, 0.25]),
+                      "pattern": np.asarray(["00AB", None], object)})
+    ea.writeReport(rep2, str(tmp_path / "pat.tsv"))
+    assert (tmp_path / "pat.tsv").read_text() == "strand\tbeta\tpattern\n+\t\t00AB\n-\t0.25\t\n"
+
+
 def test_no_timing_switches_in_the_product_library():
     """Timing builds (phases skipped: wrong results by design) are a compile-time make target; the shipped library
     must not contain the environment switches of round 1."""

@@ -73,3 +73,107 @@ def test_bad_files_raise(ea, name, kw, needle):
     with pytest.raises(ValueError) as ei:
         ea.preprocessBam(os.path.join(BAM, name), **kw)
     assert needle in str(ei.value)
+
+
+# ---- bounded windows: the file is inflated and packed piece by piece; every seam must be invisible --------------------
+
+@pytest.mark.parametrize("name,kw", [
+    ("capture.bam", {}), ("capture.bam", dict(nthreads=3, trim=2)), ("amplicon010meth.bam", {}),
+    ("dragen-se-unsort-xg-xm.bam", {}), ("dragen-pe-namesort-xg-xm.bam", {}),
+])
+@pytest.mark.parametrize("window_kib", [1, 7, 64])
+def test_windowed_packer_equals_one_pass(ea, name, kw, window_kib):
+    """window_kib = 1: every window is a single BGZF block, so records and mate pairs straddle almost every seam."""
+    whole = ea.preprocessBam(os.path.join(BAM, name), **kw)
+    piecewise = ea.preprocessBam(os.path.join(BAM, name), window_kib=window_kib, **kw)
+    for k in ("xm", "off", "rname", "strand", "start"):
+        assert np.array_equal(whole.host[k], piecewise.host[k]), k
+    assert whole.nrecs == piecewise.nrecs and whole.levels == piecewise.levels
+
+
+def test_windowed_synthetic_paired_file(ea, tmp_path):
+    from epialleler_amd import synth
+    path, nrec = synth.write_bam_paired(str(tmp_path / "pe.bam"), 30000, threads=2)
+    a = ea.preprocessBam(path, nthreads=4)
+    b = ea.preprocessBam(path, nthreads=3, window_kib=200)
+    assert a.n == 30000 and a.nrecs == nrec == b.nrecs and a.paired
+    for k in ("xm", "off", "rname", "strand", "start"):
+        assert np.array_equal(a.host[k], b.host[k]), k
+
+
+# ---- malformed input: an error message, never an out-of-bounds access ----------------------------------------------------
+
+def _raw_bam(path, records, refs=(("chrS", 100000),), text="@HD\tVN:1.0\tSO:unknown\n"):
+    import struct
+    import zlib
+    body = bytearray(b"BAM\1") + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for nm, ln in refs:
+        body += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    for r in records:                                       # bytes, or (declared block_size, bytes)
+        body += struct.pack("<i", r[0]) + r[1] if isinstance(r, tuple) else struct.pack("<i", len(r)) + r
+
+    def block(data):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(bytes(data)) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(bytes(data)) & 0xFFFFFFFF, len(data)))
+    with open(path, "wb") as f:
+        for i in range(0, len(body), 60000):
+            f.write(block(body[i:i + 60000]))
+        f.write(block(b""))
+    return str(path)
+
+
+def _rec(qname=b"r1\0", flag=0, pos=10, l_seq=8, cigar=((0, 8),), xm=b"z..Z.h.x", xg=b"CT", tid=0, mpos=-1, tlen=0, mapq=60,
+         l_seq_field=None, seq_bytes=None):
+    import struct
+    l_seq_field = l_seq if l_seq_field is None else l_seq_field
+    core = struct.pack("<iiBBHHHiiii", tid, pos, len(qname), mapq, 4680, len(cigar), flag, l_seq_field, tid if mpos >= 0 else -1, mpos, tlen)
+    cg = b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in cigar)
+    seq = bytes([0x12] * ((l_seq + 1) // 2)) if seq_bytes is None else seq_bytes
+    aux = b"XMZ" + xm + b"\0" + b"XGZ" + xg + b"\0"
+    return core + qname + cg + seq + bytes([40] * l_seq) + aux
+
+
+def test_well_formed_crafted_records(ea, tmp_path):
+    ok = ea.preprocessBam(_raw_bam(tmp_path / "ok.bam", [_rec(qname=b"a\0"), _rec(qname=b"b\0", pos=30)]))
+    assert ok.n == 2 and ok.nbytes == 16
+    # paired-end mates whose CIGARs end in a deletion: the template is as wide as the last reference position reached
+    pe = [_rec(qname=b"p\0", flag=99, pos=100, mpos=104, tlen=8, cigar=((0, 8), (2, 5))),
+          _rec(qname=b"p\0", flag=147, pos=104, mpos=100, tlen=-8, cigar=((0, 8), (2, 7)))] * 1
+    b = ea.preprocessBam(_raw_bam(tmp_path / "pe.bam", pe))
+    assert b.n == 1 and b.nbytes == 4 + 8 + 7 and np.all(b.host["xm"][12:] == 0xFB)
+
+
+@pytest.mark.parametrize("bad,needle", [
+    (dict(l_seq_field=-5), "corrupt BAM record"),
+    (dict(qname=b"xy"), "corrupt BAM record"),                                   # no NUL at the end of the name
+    (dict(cigar=((0, 12),)), "CIGAR does not match"),                            # consumes more bases than stored
+    (dict(cigar=((0, 5),)), "CIGAR does not match"),
+    (dict(xm=b"z.."), "XM tag shorter"),
+    (dict(tid=7), "reference id out of range"),
+    (dict(l_seq_field=1 << 28), "corrupt BAM record"),                           # sizes beyond the block
+])
+def test_malformed_records_are_rejected(ea, tmp_path, bad, needle):
+    recs = [_rec(qname=b"g%d\0" % i, pos=10 + i) for i in range(3)] + [_rec(**bad)]
+    with pytest.raises(ValueError) as ei:
+        ea.preprocessBam(_raw_bam(tmp_path / "bad.bam", recs), window_kib=1)
+    assert needle in str(ei.value)
+
+
+def test_malformed_pairs_and_truncation(ea, tmp_path):
+    pe = [_rec(qname=b"p\0", flag=99, pos=100, mpos=108, tlen=16), _rec(qname=b"p\0", flag=147, pos=50, mpos=100, tlen=-16)]
+    with pytest.raises(ValueError) as ei:
+        ea.preprocessBam(_raw_bam(tmp_path / "pe.bam", pe))
+    assert "starts before its template" in str(ei.value)
+    good = _raw_bam(tmp_path / "good.bam", [_rec(qname=b"g%d\0" % i, pos=10 + i) for i in range(50)])
+    data = open(good, "rb").read()
+    for cut in (len(data) - 40, len(data) // 2, 30):
+        p = tmp_path / ("cut%d.bam" % cut)
+        p.write_bytes(data[:cut])
+        with pytest.raises(ValueError):
+            ea.preprocessBam(str(p))
+    # a record whose block_size runs past the end of the stream
+    with pytest.raises(ValueError) as ei:
+        ea.preprocessBam(_raw_bam(tmp_path / "long.bam", [_rec(), (len(_rec()) + 100, _rec())]))
+    assert "truncated BAM record" in str(ei.value)
