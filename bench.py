@@ -45,7 +45,7 @@ WORKLOADS = {
     "cfg5": dict(rows=5_000_000, read_len=10000, kind="cx", threshold=False, report_context="CG",
                  desc="5M long-read (10 kb) templates, generateCytosineReport(threshold.reads=FALSE)"),
     # the only throughput the reference publishes (vignettes/epialleleR.Rmd:172-176): BAM on disk -> CX report on disk
-    "file": dict(rows=1_000_000, read_len=300, kind="file",
+    "file": dict(rows=500_000, read_len=300, kind="file",
                  desc="name-sorted paired-end XG/XM BAM on disk (2 x 150 bp mates per template) -> preprocessBam -> "
                       "generateCytosineReport defaults -> TSV report on disk"),
 }

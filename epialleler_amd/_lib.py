@@ -93,6 +93,12 @@ _SIGS = {
     "epi_batch_upload": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I64, C.POINTER(_VP)]),
     "epi_batch_adopt": (C.c_int, [_VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP, _I64, C.POINTER(_VP)]),
     "epi_batch_free": (None, [_VP]),
+    "epi_batch_threshold_reads": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP]),
+    "epi_batch_get_xm_beta": (C.c_int, [_VP, _CS, _CS, _VP]),
+    "epi_batch_cx_report": (C.c_int, [_VP, _VP, _CS, C.POINTER(CxTable)]),
+    "epi_batch_cytosine_report": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _CS, _VP, C.POINTER(CxTable)]),
+    "epi_batch_mhl_report": (C.c_int, [_VP, _CS, C.c_int, C.c_int, _F64, C.POINTER(MhlTable)]),
+    "epi_default_engine": (C.c_int, [C.POINTER(_VP)]),
     "epi_batch_nrows": (_I64, [_VP]),
     "epi_batch_threshold_reads_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _VP]),
     "epi_batch_get_xm_beta_dev": (C.c_int, [_VP, _CS, _CS, _VP, _VP]),

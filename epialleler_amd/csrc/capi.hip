@@ -27,10 +27,6 @@ struct BatchGuard {           // frees the temporary batch on every exit path
   epi_batch *b = nullptr;
   ~BatchGuard() { if (b) epi_batch_free(b); }
 };
-struct DevTmp {
-  void *p = nullptr;
-  ~DevTmp() { if (p) (void)hipFree(p); }
-};
 }  // namespace
 
 // per-read calls need no rname/strand/start: upload only xm + off
@@ -41,6 +37,119 @@ static int upload_xm_only(epi_engine *eng, const uint8_t *xm, const int64_t *off
 }
 
 extern "C" {
+
+// ---- resident batch, host results: what an R / C / C++ caller without device memory of its own uses --------------
+
+int epi_batch_threshold_reads(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                              const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                              double max_ooctx_meth_frac, int32_t *pass_out) {
+  if (!b || (b->n > 0 && !pass_out)) return fail(EPI_ERR_ARG, "epi_batch_threshold_reads: bad arguments");
+  if (b->n == 0) return EPI_OK;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  EPI_TRY(b->host_io.ensure((size_t)b->n * 8));
+  int32_t *d = b->host_io.as<int32_t>();
+  EPI_TRY(epi_batch_threshold_reads_dev(b, ctx_meth, ctx_unmeth, ooctx_meth ? ooctx_meth : "", ooctx_unmeth ? ooctx_unmeth : "",
+                                        min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac, d, s));
+  EPI_HIP(hipMemcpyAsync(pass_out, d, (size_t)b->n * 4, hipMemcpyDeviceToHost, s));
+  EPI_HIP(hipStreamSynchronize(s));
+  return EPI_OK;
+}
+
+int epi_batch_get_xm_beta(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, double *beta_out) {
+  if (!b || (b->n > 0 && !beta_out)) return fail(EPI_ERR_ARG, "epi_batch_get_xm_beta: bad arguments");
+  if (b->n == 0) return EPI_OK;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  EPI_TRY(b->host_io.ensure((size_t)b->n * 8));
+  double *d = b->host_io.as<double>();
+  EPI_TRY(epi_batch_get_xm_beta_dev(b, ctx_meth, ctx_unmeth, d, s));
+  EPI_HIP(hipMemcpyAsync(beta_out, d, (size_t)b->n * 8, hipMemcpyDeviceToHost, s));
+  EPI_HIP(hipStreamSynchronize(s));
+  return EPI_OK;
+}
+
+static int cx_table_to_host(epi_batch *b, int64_t nrow, hipStream_t s, epi_cx_table *out) {
+  int32_t *cols[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < 6; i++) {
+    cols[i] = static_cast<int32_t *>(malloc((size_t)(nrow > 0 ? nrow : 1) * 4));
+    if (!cols[i]) { for (int k = 0; k < i; k++) free(cols[k]); return fail(EPI_ERR_NOMEM, "out of host memory for the report table"); }
+  }
+  const int rc = epi_batch_cx_fetch_host(b, cols, s);
+  if (rc) { for (int i = 0; i < 6; i++) free(cols[i]); return rc; }
+  out->nrow = nrow;
+  out->rname = cols[0]; out->strand = cols[1]; out->pos = cols[2];
+  out->context = cols[3]; out->meth = cols[4]; out->unmeth = cols[5];
+  return EPI_OK;
+}
+
+int epi_batch_cx_report(epi_batch *b, const int32_t *pass, const char *ctx, epi_cx_table *out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_batch_cx_report: out is NULL");
+  memset(out, 0, sizeof(*out));
+  if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_cx_report: bad arguments");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  const int32_t *d_pass = nullptr;
+  if (pass && b->n > 0) {
+    EPI_TRY(b->host_io.ensure((size_t)b->n * 8));
+    EPI_HIP(hipMemcpyAsync(b->host_io.p, pass, (size_t)b->n * 4, hipMemcpyHostToDevice, s));
+    d_pass = b->host_io.as<int32_t>();
+  }
+  int64_t nrow = 0;
+  EPI_TRY(epi_batch_cx_report_dev(b, d_pass, ctx, s, &nrow));
+  return cx_table_to_host(b, nrow, s, out);
+}
+
+int epi_batch_cytosine_report(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                              const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                              double max_ooctx_meth_frac, const char *ctx, int32_t *pass_out, epi_cx_table *out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report: out is NULL");
+  memset(out, 0, sizeof(*out));
+  if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report: bad arguments");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  int32_t *d_pass = nullptr;
+  if (pass_out && b->n > 0) { EPI_TRY(b->host_io.ensure((size_t)b->n * 8)); d_pass = b->host_io.as<int32_t>(); }
+  int64_t nrow = 0;
+  EPI_TRY(epi_batch_cytosine_report_dev(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
+                                        max_ooctx_meth_frac, ctx, d_pass, s, &nrow));
+  if (d_pass) {
+    EPI_HIP(hipMemcpyAsync(pass_out, d_pass, (size_t)b->n * 4, hipMemcpyDeviceToHost, s));
+    EPI_HIP(hipStreamSynchronize(s));
+  }
+  return cx_table_to_host(b, nrow, s, out);
+}
+
+int epi_batch_mhl_report(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, epi_mhl_table *out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_batch_mhl_report: out is NULL");
+  memset(out, 0, sizeof(*out));
+  if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_mhl_report: bad arguments");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  int64_t nrow = 0;
+  EPI_TRY(epi_batch_mhl_report_dev(b, ctx, hmax, hmin, max_ooctx_meth_frac, s, &nrow));
+  const size_t m = (size_t)(nrow > 0 ? nrow : 1);
+  int32_t *ic[5];
+  double *dc[2];
+  for (int i = 0; i < 5; i++) ic[i] = static_cast<int32_t *>(malloc(m * 4));
+  for (int i = 0; i < 2; i++) dc[i] = static_cast<double *>(malloc(m * 8));
+  bool ok = true;
+  for (int i = 0; i < 5; i++) ok = ok && ic[i];
+  for (int i = 0; i < 2; i++) ok = ok && dc[i];
+  const int rc = ok ? epi_batch_mhl_fetch_host(b, ic, dc, s) : fail(EPI_ERR_NOMEM, "out of host memory for the report table");
+  if (rc) { for (int i = 0; i < 5; i++) free(ic[i]); for (int i = 0; i < 2; i++) free(dc[i]); return rc; }
+  out->nrow = nrow;
+  out->rname = ic[0]; out->strand = ic[1]; out->pos = ic[2]; out->context = ic[3]; out->coverage = ic[4];
+  out->length = dc[0]; out->lmhl = dc[1];
+  return EPI_OK;
+}
+
+int epi_default_engine(epi_engine **out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_default_engine: out is NULL");
+  return default_engine(out);
+}
+
+// ---- the four drop-in entry points: upload, the resident call, free ----------------------------------------------
 
 int epi_threshold_reads(const uint8_t *xm, const int64_t *off, int64_t n, const char *ctx_meth,
                         const char *ctx_unmeth, const char *ooctx_meth, const char *ooctx_unmeth,
@@ -53,14 +162,8 @@ int epi_threshold_reads(const uint8_t *xm, const int64_t *off, int64_t n, const 
   BatchGuard g;
   std::vector<int32_t> z;
   EPI_TRY(upload_xm_only(eng, xm, off, n, g, z));
-  DevTmp d;
-  EPI_HIP(hipMalloc(&d.p, (size_t)n * 4));
-  EPI_TRY(epi_batch_threshold_reads_dev(g.b, ctx_meth, ctx_unmeth, ooctx_meth ? ooctx_meth : "",
-                                        ooctx_unmeth ? ooctx_unmeth : "", min_n_ctx, min_ctx_meth_frac,
-                                        max_ooctx_meth_frac, static_cast<int32_t *>(d.p), eng->stream));
-  EPI_HIP(hipMemcpyAsync(pass_out, d.p, (size_t)n * 4, hipMemcpyDeviceToHost, eng->stream));
-  EPI_HIP(hipStreamSynchronize(eng->stream));
-  return EPI_OK;
+  return epi_batch_threshold_reads(g.b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
+                                   max_ooctx_meth_frac, pass_out);
 }
 
 int epi_get_xm_beta(const uint8_t *xm, const int64_t *off, int64_t n, const char *ctx_meth, const char *ctx_unmeth,
@@ -72,12 +175,7 @@ int epi_get_xm_beta(const uint8_t *xm, const int64_t *off, int64_t n, const char
   BatchGuard g;
   std::vector<int32_t> z;
   EPI_TRY(upload_xm_only(eng, xm, off, n, g, z));
-  DevTmp d;
-  EPI_HIP(hipMalloc(&d.p, (size_t)n * 8));
-  EPI_TRY(epi_batch_get_xm_beta_dev(g.b, ctx_meth, ctx_unmeth, static_cast<double *>(d.p), eng->stream));
-  EPI_HIP(hipMemcpyAsync(beta_out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, eng->stream));
-  EPI_HIP(hipStreamSynchronize(eng->stream));
-  return EPI_OK;
+  return epi_batch_get_xm_beta(g.b, ctx_meth, ctx_unmeth, beta_out);
 }
 
 int epi_cx_report(const uint8_t *xm, const int64_t *off, const int32_t *rname, const int32_t *strand,
@@ -89,24 +187,7 @@ int epi_cx_report(const uint8_t *xm, const int64_t *off, const int32_t *rname, c
   EPI_TRY(default_engine(&eng));
   BatchGuard g;
   EPI_TRY(epi_batch_upload(eng, xm, off, rname, strand, start, n, &g.b));
-  DevTmp d;
-  if (pass && n > 0) {
-    EPI_HIP(hipMalloc(&d.p, (size_t)n * 4));
-    EPI_HIP(hipMemcpyAsync(d.p, pass, (size_t)n * 4, hipMemcpyHostToDevice, eng->stream));
-  }
-  int64_t nrow = 0;
-  EPI_TRY(epi_batch_cx_report_dev(g.b, static_cast<const int32_t *>(d.p), ctx, eng->stream, &nrow));
-  int32_t *cols[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  for (int i = 0; i < 6; i++) {
-    cols[i] = static_cast<int32_t *>(malloc((size_t)(nrow > 0 ? nrow : 1) * 4));
-    if (!cols[i]) { for (int k = 0; k < i; k++) free(cols[k]); return fail(EPI_ERR_NOMEM, "epi_cx_report: out of host memory"); }
-  }
-  int rc = epi_batch_cx_fetch_host(g.b, cols, eng->stream);
-  if (rc) { for (int i = 0; i < 6; i++) free(cols[i]); return rc; }
-  out->nrow = nrow;
-  out->rname = cols[0]; out->strand = cols[1]; out->pos = cols[2];
-  out->context = cols[3]; out->meth = cols[4]; out->unmeth = cols[5];
-  return EPI_OK;
+  return epi_batch_cx_report(g.b, pass, ctx, out);
 }
 
 int epi_mhl_report(const uint8_t *xm, const int64_t *off, const int32_t *rname, const int32_t *strand,
@@ -119,22 +200,7 @@ int epi_mhl_report(const uint8_t *xm, const int64_t *off, const int32_t *rname, 
   EPI_TRY(default_engine(&eng));
   BatchGuard g;
   EPI_TRY(epi_batch_upload(eng, xm, off, rname, strand, start, n, &g.b));
-  int64_t nrow = 0;
-  EPI_TRY(epi_batch_mhl_report_dev(g.b, ctx, hmax, hmin, max_ooctx_meth_frac, eng->stream, &nrow));
-  const size_t m = (size_t)(nrow > 0 ? nrow : 1);
-  int32_t *ic[5];
-  double *dc[2];
-  for (int i = 0; i < 5; i++) ic[i] = static_cast<int32_t *>(malloc(m * 4));
-  for (int i = 0; i < 2; i++) dc[i] = static_cast<double *>(malloc(m * 8));
-  bool ok = true;
-  for (int i = 0; i < 5; i++) ok = ok && ic[i];
-  for (int i = 0; i < 2; i++) ok = ok && dc[i];
-  int rc = ok ? epi_batch_mhl_fetch_host(g.b, ic, dc, eng->stream) : fail(EPI_ERR_NOMEM, "epi_mhl_report: out of host memory");
-  if (rc) { for (int i = 0; i < 5; i++) free(ic[i]); for (int i = 0; i < 2; i++) free(dc[i]); return rc; }
-  out->nrow = nrow;
-  out->rname = ic[0]; out->strand = ic[1]; out->pos = ic[2]; out->context = ic[3]; out->coverage = ic[4];
-  out->length = dc[0]; out->lmhl = dc[1];
-  return EPI_OK;
+  return epi_batch_mhl_report(g.b, ctx, hmax, hmin, max_ooctx_meth_frac, out);
 }
 
 }  // extern "C"

@@ -104,7 +104,7 @@ struct epi_batch {
   epi::DevBuf mhl_m, mhl_h, mhl_blk, mhl_cont, mhl_cur;   // lMHL pass 1: stretch records, per-read info, record table, block carries
   size_t mhl_rec_cap = 0;   // records that fit mhl_m
   epi::DevBuf heavy_list, heavy_slab, heavy_sums;   // ultra-deep tiles: ids and dense counters (+ lMHL sums)
-  epi::DevBuf diag;                     // timing experiments only
+  epi::DevBuf diag;                     // check / timing builds only
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
@@ -113,6 +113,7 @@ struct epi_batch {
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes
   uint32_t cx_last_ctx_of_plane = 0;
   epi::DevBuf pass_tmp;                        // pass flags when thresholding could not be fused and the caller wants none
+  epi::DevBuf host_io;                         // device side of the host-pointer calls (pass flags / per-read beta)
   epi::DevBuf thr_tab;                         // fused thresholding: decision table for thr_tab_prm over totals 0..thr_tab_len
   int32_t thr_tab_len = -1;
   epi::ThrParams thr_tab_prm = {0, 0.0, 0.0};
@@ -157,6 +158,23 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h
 // profiling
 void prof_begin(const char *name, hipStream_t s);
 void prof_end(const char *name, hipStream_t s);
+
+// Check build (`make check`: -DEPI_CHECK -DEPI_MHL_CHECK -> libepihip_check.so): the tile kernels verify the global
+// addresses and pool indices they are about to use and record the first violation {code, v0, v1, block, thread}
+// instead of performing the access; the host turns it into EPI_ERR_STATE.  Compiled out of the product library.
+#ifdef __HIPCC__
+#ifdef EPI_CHECK
+__device__ __forceinline__ bool epi_dev_check(uint32_t *dbg, bool ok, uint32_t code, int64_t v0, int64_t v1) {
+  if (!ok && dbg && atomicCAS(dbg, 0u, code) == 0u) {
+    dbg[1] = (uint32_t)v0; dbg[2] = (uint32_t)v1; dbg[3] = blockIdx.x; dbg[4] = threadIdx.x; dbg[5] = (uint32_t)(v0 >> 32);
+  }
+  return ok;
+}
+#define EPI_DEV_CHECK(dbg, ok, code, v0, v1) epi_dev_check(dbg, ok, code, v0, v1)
+#else
+#define EPI_DEV_CHECK(dbg, ok, code, v0, v1) true
+#endif
+#endif
 
 // context-string helpers (host)
 // Wave-level scans and reductions as DPP moves (row_shr 1, 2, 4, 8 inside a row of 16 lanes, then row_bcast:15 into

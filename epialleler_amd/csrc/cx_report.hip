@@ -90,6 +90,8 @@ struct Cx2Args {
   uint32_t *heavy_count, *heavy_max;      // number of heavy tiles, largest candidate-row count among them
   uint32_t *heavy_list;                   // their tile ids (order of discovery)
   int32_t *heavy_slab;                    // [heavy tile][16][T] summed over the work items
+  uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
+  int64_t nrows;                          // rows of the batch (check build)
 };
 
 template <int T, int NP> struct Cx2Lds {
@@ -232,6 +234,11 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
     }
   } else {
     const uint8_t *p = g.base + CX_CH * (int64_t)cb;
+    {                                                     // (check build) every chunk this lane loads lies inside the buffer
+      const int64_t a_lo = p - a.c.xm, a_hi = a_lo + (tl >= 0 ? CX_CH * (int64_t)((tl / G) * G) + CX_CH : 0);
+      (void)a_lo; (void)a_hi;
+      if (!EPI_DEV_CHECK(a.dbg, tl < 0 || (a_lo >= 0 && a_hi <= a.xm_cap && (tl / G) < NU), 21, a_lo, a_hi)) return;
+    }
     if (EPI_CX_ABLATE & 1) p = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
 #pragma unroll
     for (int u = 0; u < NU; u++) {
@@ -372,6 +379,7 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
   RowVals v = cx_load_row(a.c, tb, r);
   for (int rbase = row_lo + wave * R; rbase < row_hi; rbase += NW * R) {
     const int rcur = r;
+    if (!EPI_DEV_CHECK(a.dbg, !v.ok || (rcur >= 0 && rcur < a.nrows && v.len >= 0 && (v.sd == 1 || v.sd == 2 || v.len == 0)), 22, rcur, v.sd)) return;
     r += NW * R;
     RowVals nv;
     bool fetched = false;
@@ -579,6 +587,7 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
     for (int jj = 0; jj < IT; jj++) {
       if (ok[jj]) {
         const uint32_t w = w0 + off[jj];
+        if (!EPI_DEV_CHECK(a.dbg, w < a.pool_cap, 23, w, a.pool_cap)) continue;
         a.pool_key[w] = key[jj];
         a.pool_meth[w] = me[jj];
         a.pool_unmeth[w] = un[jj];
@@ -1022,6 +1031,12 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   b->cx_last_np = np;
   b->cx_last_ctx_of_plane = a.ctx_of_plane;
   EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, CX_WG, "CX tile kernel"));
+  a.nrows = b->n;
+#ifdef EPI_CHECK
+  EPI_TRY(b->diag.ensure(256));
+  a.dbg = b->diag.as<uint32_t>();
+  EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
+#endif
   uint32_t used_total[2] = {0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
@@ -1055,6 +1070,14 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     }
     used_total[0] = host[0];
     used_total[1] = host[1];
+#ifdef EPI_CHECK
+    {
+      uint32_t d[8];
+      EPI_HIP(hipMemcpy(d, a.dbg, 32, hipMemcpyDeviceToHost));
+      if (d[0]) return fail(EPI_ERR_STATE, "CX index check %u failed: v0=%lld v1=%d block=%u thread=%u (n=%lld nt=%d attempt=%d)", d[0],
+                            (long long)(((uint64_t)d[5] << 32) | d[1]), (int)d[2], d[3], d[4], (long long)b->n, nt, attempt);
+    }
+#endif
     if (ovf_base + used_total[0] + headroom <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
     EPI_TRY(ensure_pool(b, ovf_base + used_total[0] + (used_total[0] >> 4) + 1024 + headroom));   // exact need is known now: rerun once

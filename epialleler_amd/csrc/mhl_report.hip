@@ -1023,6 +1023,8 @@ struct MhlFArgs {
   uint32_t *cursor, *tile_nrow, *tile_base;
   uint32_t *deep;                         // tiles with too many candidate rows for this kernel (the caller falls back)
   int max_rows;
+  uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
+  int64_t nrows;
 };
 
 struct __attribute__((packed, aligned(1))) MhlU4u { uint32_t x, y, z, w; };
@@ -1055,7 +1057,7 @@ __device__ __forceinline__ ChunkRaw<C> mhlf_chunk_load(const uint8_t *__restrict
   }
 #pragma unroll
   for (int j = 0; j < C; j++) {
-    if (j == 0 || g0 + 16 * j < re) {
+    if (j == 0 || g0 + 16 * j < re) {                      // (g0 >= 0 and g0 + W <= cap here: the edge path took the rest)
       const MhlU4u w = *reinterpret_cast<const MhlU4u *>(xm + g0 + 16 * j);
       r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
     }
@@ -1204,6 +1206,7 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
   for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
     const int r = rbase + grp;
     const bool valid = r < td.row_hi;
+    if (!EPI_DEV_CHECK(a.dbg, !valid || (r >= 0 && r < a.nrows && n_re >= n_rs && n_re - n_rs <= (int64_t)G * W), 31, r, n_re - n_rs)) return;
     const int64_t rs = n_rs, re = n_re;
     const int32_t st = n_st, sd = n_sd;
     const int32_t rel = (int32_t)((uint32_t)st - (uint32_t)td.pos0);       // tile position of the row's byte 0
@@ -1362,6 +1365,7 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if (ok[i]) {
+        if (!EPI_DEV_CHECK(a.dbg, w < a.pool_cap, 33, w, a.pool_cap)) continue;
         a.pool_key[w] = key[i];
         a.pool_cov[w] = ncall[i];
         a.pool_hs[w] = hs[i];
@@ -1555,6 +1559,12 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;
   EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, MHLF_WG, "lMHL tile kernel"));
+  a.nrows = b->n;
+#ifdef EPI_CHECK
+  EPI_TRY(b->diag.ensure(256));
+  a.dbg = b->diag.as<uint32_t>();
+  EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
+#endif
   uint32_t host[3] = {0, 0, 0};
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
@@ -1570,6 +1580,14 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
     EPI_TRY(read_scalars(b, s, cursor, 12, host));         // {overflow rows handed out, total rows, deep tiles}
+#ifdef EPI_CHECK
+    {
+      uint32_t d[8];
+      EPI_HIP(hipMemcpy(d, a.dbg, 32, hipMemcpyDeviceToHost));
+      if (d[0]) return fail(EPI_ERR_STATE, "fused lMHL index check %u failed: v0=%d v1=%d block=%u thread=%u (n=%lld nt=%d)", d[0],
+                            (int)d[1], (int)d[2], d[3], d[4], (long long)b->n, nt);
+    }
+#endif
     if (host[2] > 0) return EPI_OK;                        // a tile with more rows than u8 counters take: two-kernel path
     if (ovf_base + host[0] <= a.pool_cap) break;
     if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");

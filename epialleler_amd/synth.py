@@ -165,8 +165,21 @@ def write_bam_paired(path, n_pairs, n_chr=4, read_len=150, depth=30, seed=42, th
     a["seq"] = np.asarray([0x11, 0x22, 0x44, 0x88, 0x12, 0x48, 0x21, 0x84], np.uint8)[rng.integers(0, 8, (n, (L + 1) // 2))]
     a["qual"] = 37
     a["xmtag"] = np.frombuffer(b"XMZ", np.uint8)
-    letters = np.frombuffer(b".hxzuHXZ", np.uint8)
-    a["xm"] = letters[rng.choice(8, size=(n, L), p=[0.76, 0.128, 0.057, 0.030, 0.01, 0.007, 0.003, 0.005])]
+    # one context track per chromosome position (every read sees the same cytosine context at a position, as a
+    # genome gives it), methylation per read: CpG 90 % in one read out of ten, 5 % otherwise; other contexts 1 %
+    track = np.frombuffer(b".hxzu", np.uint8)[rng.choice(5, size=(n_chr, chr_len), p=[0.76, 0.135, 0.06, 0.035, 0.01])]
+    hyper = np.repeat(rng.random(n_pairs) < 0.1, 2)
+    xm = a["xm"]
+    flat = track.reshape(-1)
+    ar = np.arange(L, dtype=np.int64)[None, :]
+    for lo in range(0, n, 1 << 17):
+        hi = min(lo + (1 << 17), n)
+        base = a["refid"][lo:hi].astype(np.int64) * chr_len + a["pos"][lo:hi].astype(np.int64)
+        t = flat[base[:, None] + ar]
+        u = rng.integers(0, 256, t.shape, dtype=np.uint8)         # thresholds in 1/256: 230 = 0.9, 13 = 0.05, 3 = 0.01
+        thr = np.where(t == ord("z"), np.where(hyper[lo:hi, None], np.uint8(230), np.uint8(13)), np.uint8(3))
+        meth = (t != ord(".")) & (u < thr)
+        xm[lo:hi] = np.where(meth, t - np.uint8(32), t)            # upper case = methylated
     a["xg"][0::2] = np.where(fwd[:, None], np.frombuffer(b"XGZCT\0", np.uint8), np.frombuffer(b"XGZGA\0", np.uint8))
     a["xg"][1::2] = a["xg"][0::2]
     text = ("@HD\tVN:1.0\tSO:queryname\n" + "".join("@SQ\tSN:chrB%d\tLN:%d\n" % (i + 1, chr_len) for i in range(n_chr))).encode()

@@ -156,6 +156,24 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off,
                      const int32_t *rname, const int32_t *strand, const int32_t *start,
                      int64_t n, epi_batch **out);
 
+/* The same four computations on a batch that is already resident, host results out: what a binding without device
+ * memory of its own (the Rcpp shim) calls after ONE epi_batch_upload per preprocessBam()
+ * object.  They run on the engine's own stream and return when the results are in the caller's buffers.
+ * epi_batch_cytosine_report is generateCytosineReport(threshold.reads=TRUE) in one pass over the bytes
+ * (epi_batch_cytosine_report_dev below); pass_out is optional. */
+int epi_batch_threshold_reads(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                              const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                              double max_ooctx_meth_frac, int32_t *pass_out /* [n] */);
+int epi_batch_get_xm_beta(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, double *beta_out /* [n] */);
+int epi_batch_cx_report(epi_batch *b, const int32_t *pass /* host, may be NULL = all TRUE */, const char *ctx, epi_cx_table *out);
+int epi_batch_cytosine_report(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                              const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                              double max_ooctx_meth_frac, const char *ctx, int32_t *pass_out /* host, may be NULL */,
+                              epi_cx_table *out);
+int epi_batch_mhl_report(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, epi_mhl_table *out);
+/* the lazily created engine the host-pointer entry points use (device EPIHIP_DEVICE, default 0) */
+int epi_default_engine(epi_engine **out);
+
 /* Zero-copy: the caller (e.g. a torch tensor) owns the device buffers, keeps
  * them alive and does not change them while the batch exists.  d_xm must be
  * 16-byte aligned and xm_capacity (bytes allocated) >= off[n] rounded up to
