@@ -1265,23 +1265,23 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
         fl |= f8[d];
         if (nb != 0u && (uint32_t)((P0 >> 2) + d) < (uint32_t)Q) atomicAdd(n8 + d, nb);
       }
-      // rare bytes: skipped (coverage -1), nibble 9 (coverage +1), stray nibbles 3 / 4 / 8 (+1 on the sum their counter is)
-      if (__builtin_expect((fl & 0xE4E4E4E4u) != 0u, 0)) {
-#pragma unroll
+      // rare bytes: skipped (coverage -1 over their runs), nibble 9 (coverage +1), stray nibbles 3 / 4 / 8 (+1 on the sum
+      // their counter is).  Kept compact (bit planes + loops over set bits): unrolled per byte it was most of the kernel's
+      // code and spilled scalar registers in the hot path.
+      if (__builtin_expect(c.K != 0, 0))
+        mhlf_for_runs<W>(c.K, false, c, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(s_cov, P0 + f, P0 + f + e, (unsigned long long)(0u - unit)); });
+      if (__builtin_expect((fl & 0xE0E0E0E0u) != 0u, 0)) {
+        M dbl = 0, s_lo = 0, s_hi = 0;                                       // planes of flag bits 5 (doubled), 6, 7 (stray id)
         for (int d = 0; d < 4 * C; d++) {
-          if ((f8[d] & 0xE4E4E4E4u) == 0u) continue;
-          for (int j = 0; j < 4; j++) {
-            const uint32_t fb = (f8[d] >> (8 * j)) & 0xE4u;
-            if (!fb || !(((uint64_t)c.V >> (4 * d + j)) & 1ull)) continue;    // (flags of bytes outside the row are not cleared)
-            const int p = P0 + 4 * d + j;
-            if (fb & 4u) mhlf_interval(s_cov, p, p + 1, (unsigned long long)(0u - unit));
-            if (fb & 32u) mhlf_interval(s_cov, p, p + 1, unit);
-            const uint32_t sid = fb >> 6;
-            if (sid == 1u) mhlf_interval(dn, p, p + 1, 1ull);
-            else if (sid == 2u) mhlf_interval(dd, p, p + 1, 1ull);
-            else if (sid == 3u) mhlf_interval(dh, p, p + 1, 1ull);
-          }
+          dbl |= (M)plane_nibble(f8[d], 5) << (4 * d);
+          s_lo |= (M)plane_nibble(f8[d], 6) << (4 * d);
+          s_hi |= (M)plane_nibble(f8[d], 7) << (4 * d);
         }
+        dbl &= c.V; s_lo &= c.V; s_hi &= c.V;                                // (flags of bytes outside the row are not cleared)
+        for (M m = dbl; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(s_cov, p, p + 1, unit); }
+        for (M m = s_lo & ~s_hi; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dn, p, p + 1, 1ull); }     // nibble 3
+        for (M m = s_hi & ~s_lo; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dd, p, p + 1, 1ull); }     // nibble 4
+        for (M m = s_lo & s_hi; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dh, p, p + 1, 1ull); }      // nibble 8
       }
     }
   }
