@@ -265,6 +265,9 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
     cx2_chunk_masks(cb == g.c0 ? (g.rel & 15) : 0, CX_CH, mf);
     cx2_chunk_masks(0, ((g.rel + g.len - 1) & 15) + 1, ml);
 #pragma unroll
+    for (int d = 0; d < 4; d++) { asm("" : "+v"(mf[d])); asm("" : "+v"(ml[d])); }   // computed once per visit: hipcc otherwise
+                                                                                    // re-derives them at every dword (14 VALU each)
+#pragma unroll
     for (int d = 0; d < 4; d++) w[0][d] = (w[0][d] & mf[d]) | (a.fill4 & ~mf[d]);
 #pragma unroll
     for (int u = 0; u < NU; u++) {
