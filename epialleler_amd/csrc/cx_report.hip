@@ -759,6 +759,162 @@ __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(Cx2Args a, const int32_t
   cx2_emit_from_slab<T, NP>(a, tile, a.slab + (int64_t)a.tiles[tile].slot * (kCxPlanes * T));
 }
 
+// ---- reports of two or three contexts (CxG, CX): one u16-pair LDS atomic per base --------------------------------------
+// With several reported contexts nearly every dword of a read holds a call, so the u8 scheme above would issue an LDS
+// atomic per dword and context; here a base is one ds_add_u32 into packed u16 pairs [strand][('.',other),(H,h),(X,x),
+// (Z,z)][T] with the byte order rotated per lane so that the 32 lanes of a half-wave hit 32 different banks
+// (tile_common.hpp: cx_add_dword).  After the rows the counters are rewritten in place into what the common emit
+// reads: plane 0 = coverage, context planes = n | M << 16.
+constexpr int CXP_T = 1024;
+
+template <int G, int U0, int U1>
+__device__ __forceinline__ void cxp_add_range(const uint32_t (&w)[CX_NU], const RowSlice &cur) {
+  if constexpr (U0 < U1) {
+    if (U0 * G <= cur.tl) cx_add_dword<CXP_T, 4 * G * U0, U0 == 0, true>(w[U0], cur.tl == U0 * G, cur);
+    cxp_add_range<G, U0 + 1, U1>(w, cur);
+  }
+}
+
+// G lanes own a row (64/G rows per wavefront step); a lane keeps CX_NU dword loads of the row's in-tile slice in flight
+// and the next step's row columns are fetched with them.
+template <int G>
+__device__ __forceinline__ void cxp_accumulate(const RowCols &c, const Tile &td, uint32_t *cnt) {
+  constexpr int R = 64 / G, NW = CX_WG / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (G - 1), grp = lane / G;
+  int r = td.row_lo + wave * R + grp;
+  RowSlice cur = cx_row_slice<CXP_T, G, true>(c, td, r, sub, cnt);
+  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
+    uint32_t w[CX_NU];                                    // every load of the slice is in flight before the first is used
+#pragma unroll
+    for (int u = 0; u < CX_NU; u++) w[u] = u * G <= cur.tl ? cur.src[u * G] : 0u;
+    r += NW * R;
+    const RowSlice nxt = cx_row_slice<CXP_T, G, true>(c, td, r, sub, cnt);
+    cxp_add_range<G, 0, CX_NU>(w, cur);
+    for (int k = sub + CX_NU * G; k < cur.nd; k += G) {   // slices longer than CX_NU*G dwords
+      RowSlice t = cur;
+#pragma unroll
+      for (int j = 0; j < 4; j++) t.dst[j] = cur.dst[j] + 4 * (k - sub);
+      cx_add_dword<CXP_T, 0, false, true>(cur.src[k - sub], k == cur.nd - 1, t);
+    }
+    cur = nxt;
+  }
+}
+
+// packed pairs -> plane 0: coverage (:126-127: every counted base, nibble 9 twice), planes 1-3: n | M << 16 of H, X, Z
+__device__ __forceinline__ void cxp_convert(uint32_t *cnt) {
+  constexpr int T = CXP_T;
+  for (int i = threadIdx.x; i < 2 * T; i += CX_WG) {
+    uint32_t *c0 = cnt + (i / T) * 4 * T + (i % T);
+    const uint32_t d0 = c0[0], dh = c0[T], dx = c0[2 * T], dz = c0[3 * T];
+    const uint32_t nh = (dh & 0xFFFFu) + (dh >> 16), nx = (dx & 0xFFFFu) + (dx >> 16), nz = (dz & 0xFFFFu) + (dz >> 16);
+    c0[0] = (d0 & 0xFFFFu) + (d0 >> 16) + nh + nx + nz;
+    c0[T] = nh | (dh << 16);
+    c0[2 * T] = nx | (dx << 16);
+    c0[3 * T] = nz | (dz << 16);
+  }
+}
+
+struct CxSrcPk {                          // the converted counters as the emit phase's source
+  const uint32_t *cnt;
+  int pl[3];                              // counter plane (1 = H, 2 = X, 3 = Z) of reported plane p, 0 = no such plane
+  __device__ __forceinline__ uint32_t any(int sd, int pos) const {
+    uint32_t x = 0;
+#pragma unroll
+    for (int p = 0; p < 3; p++) if (pl[p]) x |= cnt[(sd * 4 + pl[p]) * CXP_T + pos];
+    return x;
+  }
+  __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *n, uint32_t *M) const {
+    const uint32_t w = pl[p] ? cnt[(sd * 4 + pl[p]) * CXP_T + pos] : 0u;
+    *n = w & 0xFFFFu; *M = w >> 16;
+  }
+  __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { return cnt[sd * 4 * CXP_T + pos]; }
+};
+
+__device__ __forceinline__ CxSrcPk cxp_source(const Cx2Args &a, const uint32_t *cnt) {
+  CxSrcPk s;
+  s.cnt = cnt;
+#pragma unroll
+  for (int p = 0; p < 3; p++) { const uint32_t k = (a.ctx_of_plane >> (8 * p)) & 255u; s.pl[p] = k == 2u ? 1 : k == 6u ? 2 : k == 7u ? 3 : 0; }
+  return s;
+}
+
+// converted counters -> slab [16][T] in the common format ((n, M) per strand and reported plane, coverage as differences)
+__device__ __forceinline__ void cxp_dump_slab(const Cx2Args &a, const uint32_t *cnt, int np, int32_t *slab) {
+  constexpr int T = CXP_T;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
+  const CxSrcPk src = cxp_source(a, cnt);
+  for (int i = threadIdx.x; i < 2 * T; i += CX_WG) {
+    const int sd = i / T, pos = i % T;
+    for (int p = 0; p < np; p++) {
+      uint32_t n, M;
+      src.pair(sd, p, pos, &n, &M);
+      if (n) atomicAdd(dst + (2 * (sd * np + p)) * T + pos, n);
+      if (M) atomicAdd(dst + (2 * (sd * np + p) + 1) * T + pos, M);
+    }
+    const uint32_t d = src.coverage(sd, pos) - (pos ? src.coverage(sd, pos - 1) : 0u);
+    if (d) atomicAdd(dst + (CX_SLAB_COV + sd) * T + pos, d);
+  }
+}
+
+#define CXP_SHARED                                                                                      \
+  __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[8 * CXP_T + 2 * kCxGuard];                  \
+  __shared__ uint32_t s_scan[CX_WG / 64 + 2];                                                         \
+  __shared__ uint16_t s_list[2 * CXP_T];                                                               \
+  uint32_t *cnt = cnt_raw + kCxGuard;
+
+template <int G>
+__global__ __launch_bounds__(CX_WG, 8) void k_cxp_tiles(Cx2Args a, int ntiles, int np) {
+  CXP_SHARED
+  const int tile = cx_tile_of_block(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
+  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+  for (int i = threadIdx.x; i < (8 * CXP_T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  if (td.row_hi - td.row_lo > a.heavy_rows) {
+    if (threadIdx.x == 0) {
+      const uint32_t h = atomicAdd(a.heavy_count, 1u);
+      a.heavy_list[h] = (uint32_t)tile;
+      atomicMax(a.heavy_max, (uint32_t)(td.row_hi - td.row_lo));
+      a.tile_nrow[tile] = 0;
+      a.tile_base[tile] = 0;
+    }
+    return;
+  }
+  __syncthreads();
+  cxp_accumulate<G>(a.c, td, cnt);
+  __syncthreads();
+  cxp_convert(cnt);
+  __syncthreads();
+  if (td.slot >= 0) {                                     // shared with another rank: hand the sums over
+    cxp_dump_slab(a, cnt, np, a.slab + (int64_t)td.slot * (kCxPlanes * CXP_T));
+    if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+    return;
+  }
+  cx2_emit<CXP_T, 3>(a, tile, cxp_source(a, cnt), s_scan, s_list);
+}
+
+template <int G>
+__global__ __launch_bounds__(CX_WG, 8) void k_cxp_heavy(Cx2Args a, int np) {
+  CXP_SHARED
+  (void)s_scan; (void)s_list;
+  const int tile = (int)a.heavy_list[blockIdx.y];
+  Tile td = a.tiles[tile];
+  const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
+  if (lo >= td.row_hi) return;
+  td.row_lo = lo;
+  if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
+  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+  for (int i = threadIdx.x; i < (8 * CXP_T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  cxp_accumulate<G>(a.c, td, cnt);
+  __syncthreads();
+  cxp_convert(cnt);
+  __syncthreads();
+  cxp_dump_slab(a, cnt, np, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * CXP_T)
+                                          : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * CXP_T));
+}
+
 // One wavefront per tile copies the tile's rows from the pool to their place in the final table
 // (offset = exclusive scan of the tile row counts) and decodes them: contiguous reads, contiguous writes.
 __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
@@ -791,7 +947,7 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
 
 // Tile size: 2048 positions for a single reported context (40 KiB of LDS, four workgroups per CU, fewer rows that
 // reach into two tiles, fuller rounds), 1024 with two or three contexts (their counters take 32 / 44 KiB).
-static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : 1024; }
+static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : CXP_T; }
 
 // Lanes per row and 16-byte chunks per lane.  Whole rows (fused thresholding) must fit one visit of G * NU chunks
 // wherever they start inside their first chunk; slices of longer rows loop.  Returned as G * 8 + NU.
@@ -837,14 +993,43 @@ static void launch_cx_g(bool heavy, int g, int nt, dim3 grid, hipStream_t s, con
   hipLaunchKernelGGL((k_cx_emit_heavy<T, NP>), dim3(grid.y), dim3(CX_WG), 0, s, a);
 }
 
+// lanes per row of the packed-pair kernel: enough that CX_NU dwords per lane cover the longest in-tile slice
+static int pick_cxp_group(int32_t max_len) {
+  const int slice = (max_len < CXP_T ? max_len : CXP_T) + 3;
+  const int nd = (slice + 3) / 4;
+  int g = 8;
+  while (g < 64 && g * CX_NU < nd) g <<= 1;
+  return g;
+}
+
+static void launch_cxp(bool heavy, int np, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+  if (!heavy) {
+    const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
+    switch (g) {
+      case 8: hipLaunchKernelGGL((k_cxp_tiles<8>), dim3(nb), dim3(CX_WG), 0, s, a, nt, np); break;
+      case 16: hipLaunchKernelGGL((k_cxp_tiles<16>), dim3(nb), dim3(CX_WG), 0, s, a, nt, np); break;
+      case 32: hipLaunchKernelGGL((k_cxp_tiles<32>), dim3(nb), dim3(CX_WG), 0, s, a, nt, np); break;
+      default: hipLaunchKernelGGL((k_cxp_tiles<64>), dim3(nb), dim3(CX_WG), 0, s, a, nt, np); break;
+    }
+    return;
+  }
+  switch (g) {
+    case 8: hipLaunchKernelGGL((k_cxp_heavy<8>), grid, dim3(CX_WG), 0, s, a, np); break;
+    case 16: hipLaunchKernelGGL((k_cxp_heavy<16>), grid, dim3(CX_WG), 0, s, a, np); break;
+    case 32: hipLaunchKernelGGL((k_cxp_heavy<32>), grid, dim3(CX_WG), 0, s, a, np); break;
+    default: hipLaunchKernelGGL((k_cxp_heavy<64>), grid, dim3(CX_WG), 0, s, a, np); break;
+  }
+  if (np == 2) hipLaunchKernelGGL((k_cx_emit_heavy<CXP_T, 2>), dim3(grid.y), dim3(CX_WG), 0, s, a);
+  else hipLaunchKernelGGL((k_cx_emit_heavy<CXP_T, 3>), dim3(grid.y), dim3(CX_WG), 0, s, a);
+}
+
 static void launch_cx(bool heavy, int np, bool fused, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   const int g = shape >> 3, nu = shape & 7;
+  if (np > 1) { launch_cxp(heavy, np, g, nt, grid, s, a); return; }   // several contexts: one packed-pair atomic per base
   if (fused) {                                             // one context, 2048-position tiles
     if (nu == 3) launch_cx_g<CX_T1, 3, 1, true>(heavy, g, nt, grid, s, a);
     else launch_cx_g<CX_T1, 5, 1, true>(heavy, g, nt, grid, s, a);
-  } else if (np == 1) launch_cx_g<CX_T1, 3, 1, false>(heavy, g, nt, grid, s, a);
-  else if (np == 2) launch_cx_g<1024, 3, 2, false>(heavy, g, nt, grid, s, a);
-  else launch_cx_g<1024, 3, 3, false>(heavy, g, nt, grid, s, a);
+  } else launch_cx_g<CX_T1, 3, 1, false>(heavy, g, nt, grid, s, a);
 }
 
 static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
@@ -1008,7 +1193,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     slot = 0;                                              // the slots do not fit in device memory: every tile through the
     ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
-  const int grp = pick_cx_shape(st.max_len, T, fused);   // lanes per row * 8 + chunks per lane
+  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused);   // lanes per row * 8 + chunks per lane
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
 
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
