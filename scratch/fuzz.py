@@ -50,6 +50,8 @@ while time.time() < t_end:
         if cut and t["off"][-1] - t["off"][-2] > cut:
             t["off"] = t["off"].copy(); t["off"][-1] -= cut
             t["xm"] = t["xm"][:int(t["off"][-1])]
+    elif kind == 5 and it % 2:   # ragged, gapped templates at uniform-random starts (bench cfg2u's model), small
+        t = synth_np.generate_uniform(seed=seed, n_total=int(rng.integers(1000, 30000)))
     else:              # the bench generator's model, small
         t = synth_np.generate(seed=seed, n_total=int(rng.integers(1000, 30000)), read_len=int(rng.choice([100, 300, 301, 2000])))
     n = t["off"].size - 1
@@ -67,6 +69,12 @@ while time.time() < t_end:
         rctx = str(rng.choice(["Z", "X", "H", "ZX", "ZXH"]))
         H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, p, rctx)),
                                orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, rctx))
+        if n:                                                # the one-pass entry point (thresholding inside the tile kernel)
+            rctx2 = str(rng.choice(["Z", "X", "H", "ZX", "ZXH"]))
+            rep2, p2 = ea.cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], mn, mb, mo,
+                                                rctx2, return_pass=True)
+            assert np.array_equal(p2.astype(np.int32), want), ("fused pass", seed)
+            H.assert_reports_equal(dict(rep2), orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], want, rctx2))
         if not (kind == 6 and n > 200000):                   # (the lMHL oracle is slow on the big cases)
             hctx = str(rng.choice(["Zz", "Xx", "Hh", "ZzXx", "ZzXxHh"]))
             hmax, hmin, moo = int(rng.choice([0, 0, 1, 3, 50])), int(rng.choice([0, 0, 2, 5])), float(rng.choice([0.1, 0.0, 1.0]))
