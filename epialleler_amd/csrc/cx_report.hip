@@ -409,6 +409,8 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
         const uint32_t unit = g.sidx ? 65536u : 1u;
         if (ca < cb && !(EPI_CX_ABLATE & 32)) { atomicAdd(L.cov + ca, unit); if (cb < T) atomicAdd(L.cov + cb, 0u - unit); }
       }
+    } else if (FUSED && v.ok && sub == 0 && a.pass_out && (uint32_t)((uint32_t)v.st - (uint32_t)td.pos0) < (uint32_t)T) {
+      a.pass_out[rcur] = 0;             // an empty read has no call of the context: fails (rcpp_threshold_reads.cpp:43)
     }
     fetch_next();
     v = nv;

@@ -71,6 +71,7 @@ while time.time() < t_end:
                                orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, rctx))
         if n:                                                # the one-pass entry point (thresholding inside the tile kernel)
             rctx2 = str(rng.choice(["Z", "X", "H", "ZX", "ZXH"]))
+            H.dirty_allocator(bam)
             rep2, p2 = ea.cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], mn, mb, mo,
                                                 rctx2, return_pass=True)
             assert np.array_equal(p2.astype(np.int32), want), ("fused pass", seed)

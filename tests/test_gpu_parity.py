@@ -55,6 +55,7 @@ def check_all(ea, t, pass_variants=True, mhl=True, contexts=ALL_CTX):
             # thresholding fused into the tile kernel (generateCytosineReport's default path): same table, same flags
             for rctx in (ctx, "CX" if ctx == "CG" else "CG"):
                 letters = C2B[rctx]["ctx_meth"]
+                H.dirty_allocator(bam)                   # the flag column must be written for every row, empty reads too
                 got, gp = ea.cytosine_report_fused(bam, c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1,
                                                    letters, return_pass=True)
                 assert np.array_equal(gp.astype(np.int32), want), ("fused pass", ctx)
