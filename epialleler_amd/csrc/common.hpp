@@ -80,6 +80,7 @@ struct RowStats {          // filled by k_row_stats
   int32_t unsorted;        // !=0: some row violates (rname,start) order
   int32_t bad_strand;      // !=0: strand not in {1,2}
   int32_t bad_len;         // !=0: off not non-decreasing
+  int32_t deep;            // !=0: some position may be covered by more than 255 rows (row x + 255 starts inside row x)
 };
 }  // namespace epi
 

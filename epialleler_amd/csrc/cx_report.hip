@@ -67,6 +67,7 @@ struct Cx2Args {
   RowCols c;                              // c.pass: external pass vector or null (all TRUE); ignored when fused
   int64_t xm_cap;                         // readable bytes behind c.xm
   const Tile *tiles;
+  uint32_t fill4;                         // 4 x a code without any flag in either LUT (stands in for bytes outside a row)
   ClassLut lut_r;                         // report LUT: byte = [n0 M0 n1 M1 n2 M2 skip dbl] flags of a code (n: a call of
                                           // plane p's context in either case, M: a methylated one)
   ClassLut lut_s;                         // fused: bits 0,2,4,6 = in context / methylated / out-of-context methylated /
@@ -74,7 +75,6 @@ struct Cx2Args {
   ThrParams thr;
   const uint32_t *thr_tab;                // fused thresholding without divisions: [n] = least passing n_m for n_m + n_u = n
                                           // (low half), largest passing o_m for o_m + o_u = n (high half); k_thr_table
-  uint32_t fill4;                         // 4 x a code without any flag in either LUT (stands in for bytes outside a row)
   uint32_t ctx_of_plane;                  // byte p = context code (2, 6, 7) of plane p
   int32_t *pass_out;                      // fused: pass flag of every row (may be null)
   uint32_t *pool_key, *pool_meth, *pool_unmeth;
@@ -94,11 +94,13 @@ struct Cx2Args {
   int64_t nrows;                          // rows of the batch (check build)
 };
 
-template <int T, int NP> struct Cx2Lds {
+// LEAN: no position of the batch is covered by more than 255 rows (RowStats::deep == 0, tiles.hip), so the u8 counters
+// cannot overflow however many rows a tile has: no u16 copy, no folds, the emit reads the u8 counters.
+template <int T, int NP, bool LEAN = false> struct Cx2Lds {
   static constexpr int Q = T / 4;
   static constexpr int N_NARROW = 2 * NP * Q;    // u64: [strand][plane][Q], low dword = n of 4 positions (u8), high = M
   static constexpr int N_CORR = 2 * Q;           // u64: [strand][Q], low dword = skipped, high = doubled (u8 x 4)
-  static constexpr int N_WIDE = 2 * NP * T;      // u32: [strand][plane][T] = n | M << 16
+  static constexpr int N_WIDE = LEAN ? 16 : 2 * NP * T;   // u32: [strand][plane][T] = n | M << 16 (LEAN: scan scratch only)
   static constexpr int N_COV = T;                // u32: coverage difference array, '+' in the low half, '-' in the high half
                                                  // (a change "behind the tile" is simply not recorded)
   unsigned long long *narrow, *corr;
@@ -179,16 +181,6 @@ __global__ __launch_bounds__(256) void k_thr_table(ThrParams prm, int32_t nmax, 
   tab[n] = least | (most << 16);
 }
 
-// bytes [lo,hi) of a dword set to 0xFF (any sign)
-__device__ __forceinline__ uint32_t cx2_byte_range(int lo, int hi) {
-  const int l = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
-  const int h = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
-  if (h <= l) return 0u;
-  const uint32_t mh = h == 4 ? ~0u : (1u << (8 * h)) - 1u;
-  const uint32_t ml = (1u << (8 * l)) - 1u;                 // l < 4 here
-  return mh & ~ml;
-}
-
 // One visit of up to G * NU position-aligned 16-byte chunks of a row, starting at chunk cs: loads (all in flight
 // before the first is used), then -- FUSED -- the thresholding decision, then the calls.  `fetch_next` runs between
 // the loads and their first use (the caller fetches the next row's columns there).
@@ -200,15 +192,25 @@ struct Cx2Row {
   int sidx, ps;
 };
 
-// byte masks of the four dwords of a chunk whose bytes [lo, 16) (FIRST) or [0, hi) belong to the row
-__device__ __forceinline__ void cx2_chunk_masks(int lo, int hi, uint32_t (&m)[4]) {
-#pragma unroll
-  for (int d = 0; d < 4; d++) m[d] = cx2_byte_range(lo - 4 * d, hi - 4 * d);
+// Byte masks (0xFF per byte) of the four dwords of a 16-byte chunk: bytes [lo, 16) resp. [0, hi) -- a 128-bit shift
+// done as one 64-bit shift and two selects per half (the generic per-dword form cost ~35 VALU per mask)
+__device__ __forceinline__ void cx2_mask_from(int lo /* 0..15 */, uint32_t (&m)[4]) {
+  const unsigned long long x = ~0ull << ((8 * lo) & 63);
+  const bool low = lo < 8;
+  const unsigned long long a = low ? x : 0ull, b = low ? ~0ull : x;
+  m[0] = (uint32_t)a; m[1] = (uint32_t)(a >> 32); m[2] = (uint32_t)b; m[3] = (uint32_t)(b >> 32);
+}
+__device__ __forceinline__ void cx2_mask_upto(int hi /* 1..16 */, uint32_t (&m)[4]) {
+  const int sh = 8 * (16 - hi);                                     // 0..120
+  const unsigned long long x = ~0ull >> (sh & 63);
+  const bool high = sh < 64;
+  const unsigned long long a = high ? ~0ull : x, b = high ? x : 0ull;
+  m[0] = (uint32_t)a; m[1] = (uint32_t)(a >> 32); m[2] = (uint32_t)b; m[3] = (uint32_t)(b >> 32);
 }
 
-template <int T, int G, int NU, int NP, bool FUSED, class F>
+template <int T, int G, int NU, int NP, bool FUSED, class LT, class F>
 __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t cs, int32_t cz, int sub, int rcur,
-                                          const Cx2Lds<T, NP> &L, F fetch_next) {
+                                          const LT &L, F fetch_next) {
   constexpr int C = T / CX_CH, Q = T / 4;
   const int32_t cb = cs + sub;                                      // this lane's chunks: cb + u*G
   const int32_t tl = cz - cb;                                       // chunk u is part of the visit iff u*G <= tl
@@ -259,22 +261,20 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
     return;
   }
   // Bytes of the row's first / last chunk that belong to neighbouring rows -> a code without flags.  The first chunk
-  // is the first lane's first one; the last one can be any: its four masks are selected per chunk.
+  // is the first lane's first one; the last one can be any of the lane's chunks.
   {
     uint32_t mf[4], ml[4];
-    cx2_chunk_masks(cb == g.c0 ? (g.rel & 15) : 0, CX_CH, mf);
-    cx2_chunk_masks(0, ((g.rel + g.len - 1) & 15) + 1, ml);
+    cx2_mask_from(cb == g.c0 ? (g.rel & 15) : 0, mf);
+    cx2_mask_upto(((g.rel + g.len - 1) & 15) + 1, ml);
 #pragma unroll
-    for (int d = 0; d < 4; d++) { asm("" : "+v"(mf[d])); asm("" : "+v"(ml[d])); }   // computed once per visit: hipcc otherwise
-                                                                                    // re-derives them at every dword (14 VALU each)
-#pragma unroll
-    for (int d = 0; d < 4; d++) w[0][d] = (w[0][d] & mf[d]) | (a.fill4 & ~mf[d]);
+    for (int d = 0; d < 4; d++) { asm("" : "+v"(mf[d])); asm("" : "+v"(ml[d])); }    // (once per visit, not per use)
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       const bool last = cb + u * G == g.clast;
 #pragma unroll
       for (int d = 0; d < 4; d++) {
-        const uint32_t m = last ? ml[d] : 0xFFFFFFFFu;
+        uint32_t m = last ? ml[d] : 0xFFFFFFFFu;
+        if (u == 0) m &= mf[d];
         w[u][d] = (w[u][d] & m) | (a.fill4 & ~m);
       }
     }
@@ -371,8 +371,8 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
 
 // Rows [row_lo, row_hi) of the tile into the u8 counters and the coverage array.  G lanes own a row (64/G rows per
 // wavefront step); the next step's row columns are fetched while the current row's bytes are in flight.
-template <int T, int G, int NU, int NP, bool FUSED>
-__device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
+template <int T, int G, int NU, int NP, bool FUSED, class LT>
+__device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const LT &L) {
   constexpr int R = 64 / G, NW = CX_WG / 64, C = T / CX_CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
@@ -402,7 +402,11 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
         cx2_visit<T, G, NU, NP, true>(a, g, g.c0, g.clast, sub, rcur, L, fetch_next);     // the host made sure the row fits
       } else {
         const int32_t ca = g.c0 > 0 ? g.c0 : 0, cz = g.clast < C - 1 ? g.clast : C - 1;   // the slice inside the tile
-        for (int32_t cs = ca; cs <= cz; cs += G * NU) cx2_visit<T, G, NU, NP, false>(a, g, cs, cz, sub, rcur, L, fetch_next);
+        if constexpr (C + 1 <= 64 * NU) {                   // (the host picked G so that a slice is one visit: pick_cx_shape)
+          cx2_visit<T, G, NU, NP, false>(a, g, ca, cz, sub, rcur, L, fetch_next);
+        } else {
+          for (int32_t cs = ca; cs <= cz; cs += G * NU) cx2_visit<T, G, NU, NP, false>(a, g, cs, cz, sub, rcur, L, fetch_next);
+        }
       }
       if (sub == 0) {                                                 // coverage: +1 on the row's positions inside the tile
         const int32_t ca = g.rel > 0 ? g.rel : 0, cb = g.rel + v.len < T ? g.rel + v.len : T;
@@ -418,22 +422,24 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
 }
 
 // u8 counters -> u16 pairs, skipped / doubled codes -> coverage difference array.  Every cell has one owner thread.
-template <int T, int NP>
-__device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP> &L) {
+template <int T, int NP, bool LEAN>
+__device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
   constexpr int Q = T / 4;
-  for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
-    const unsigned long long v = L.narrow[i];
-    if (v == 0ull) continue;
-    L.narrow[i] = 0ull;
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    const int sp = i / Q, q = i - sp * Q;
-    uint4 *wd = reinterpret_cast<uint4 *>(L.wide + sp * T + 4 * q);
-    uint4 c = *wd;
-    c.x += (lo & 255u) | ((hi & 255u) << 16);
-    c.y += ((lo >> 8) & 255u) | (((hi >> 8) & 255u) << 16);
-    c.z += ((lo >> 16) & 255u) | (((hi >> 16) & 255u) << 16);
-    c.w += (lo >> 24) | ((hi >> 24) << 16);
-    *wd = c;
+  if constexpr (!LEAN) {
+    for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
+      const unsigned long long v = L.narrow[i];
+      if (v == 0ull) continue;
+      L.narrow[i] = 0ull;
+      const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+      const int sp = i / Q, q = i - sp * Q;
+      uint4 *wd = reinterpret_cast<uint4 *>(L.wide + sp * T + 4 * q);
+      uint4 c = *wd;
+      c.x += (lo & 255u) | ((hi & 255u) << 16);
+      c.y += ((lo >> 8) & 255u) | (((hi >> 8) & 255u) << 16);
+      c.z += ((lo >> 16) & 255u) | (((hi >> 16) & 255u) << 16);
+      c.w += (lo >> 24) | ((hi >> 24) << 16);
+      *wd = c;
+    }
   }
   for (int i = threadIdx.x; i < 2 * Q; i += CX_WG) {
     const unsigned long long v = L.corr[i];
@@ -475,6 +481,19 @@ template <int T, int NP> struct CxSrcLds {
   __device__ __forceinline__ void pair(int sd, int p, int pos, uint32_t *n, uint32_t *M) const {
     const uint32_t w = wide[(sd * NP + p) * T + pos];
     *n = w & 0xFFFFu; *M = w >> 16;
+  }
+  __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
+};
+// ... the u8 counters themselves (LEAN, one context) ...
+template <int T> struct CxSrcU8 {
+  const uint32_t *narrow;                 // the u64 cells as dword pairs: [2 * cell] = n, [2 * cell + 1] = M of 4 positions
+  const uint32_t *cov;                    // prefix-summed
+  __device__ __forceinline__ uint32_t any(int sd, int pos) const {
+    return (narrow[2 * (sd * (T / 4) + (pos >> 2))] >> (8 * (pos & 3))) & 255u;
+  }
+  __device__ __forceinline__ void pair(int sd, int, int pos, uint32_t *n, uint32_t *M) const {
+    const uint2 c = *reinterpret_cast<const uint2 *>(narrow + 2 * (sd * (T / 4) + (pos >> 2)));
+    *n = (c.x >> (8 * (pos & 3))) & 255u; *M = (c.y >> (8 * (pos & 3))) & 255u;
   }
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
 };
@@ -603,15 +622,31 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
 
 // Adds a tile's (folded) LDS sums into its dense slab [16][T] in HBM (shared tiles, heavy tiles).  The coverage
 // array goes over un-summed: difference arrays add across work items and ranks like everything else.
-template <int T, int NP>
-__device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP> &L, int32_t *slab) {
+template <int T, int NP, bool LEAN>
+__device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int32_t *slab) {
   uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
-  for (int i = threadIdx.x; i < 2 * NP * T; i += CX_WG) {
-    const uint32_t v = L.wide[i];
-    if (!v) continue;
-    const int sp = i / T, p = i - sp * T;
-    if (v & 0xFFFFu) atomicAdd(dst + (2 * sp) * T + p, v & 0xFFFFu);
-    if (v >> 16) atomicAdd(dst + (2 * sp + 1) * T + p, v >> 16);
+  if constexpr (LEAN) {
+    constexpr int Q = T / 4;
+    for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
+      const unsigned long long v = L.narrow[i];
+      if (v == 0ull) continue;
+      const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+      const int sp = i / Q, q = i - sp * Q;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t n = (lo >> (8 * j)) & 255u, M = (hi >> (8 * j)) & 255u;
+        if (n) atomicAdd(dst + (2 * sp) * T + 4 * q + j, n);
+        if (M) atomicAdd(dst + (2 * sp + 1) * T + 4 * q + j, M);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2 * NP * T; i += CX_WG) {
+      const uint32_t v = L.wide[i];
+      if (!v) continue;
+      const int sp = i / T, p = i - sp * T;
+      if (v & 0xFFFFu) atomicAdd(dst + (2 * sp) * T + p, v & 0xFFFFu);
+      if (v >> 16) atomicAdd(dst + (2 * sp + 1) * T + p, v >> 16);
+    }
   }
   for (int p = threadIdx.x; p < T; p += CX_WG) {
     const uint32_t v = L.cov[p];
@@ -633,59 +668,70 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
 }
 
 // workgroups per CU by LDS (the u8 arrays double as the emit phase's candidate lists) and the 2048-thread limit
-template <int T, int NP> constexpr int cx2_lds_bytes() {
-  return (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 + (Cx2Lds<T, NP>::N_WIDE + Cx2Lds<T, NP>::N_COV) * 4;
+template <int T, int NP, bool LEAN = false> constexpr int cx2_lds_bytes() {
+  return (Cx2Lds<T, NP, LEAN>::N_NARROW + Cx2Lds<T, NP, LEAN>::N_CORR) * 8 + (Cx2Lds<T, NP, LEAN>::N_WIDE + Cx2Lds<T, NP, LEAN>::N_COV) * 4;
 }
 #ifndef EPI_CX_WPS
 #define EPI_CX_WPS 8
 #endif
-template <int T, int NP, int NU = 3> constexpr int cx2_waves_per_simd() {
-  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP>(), by_thr = 2048 / CX_WG;
+template <int T, int NP, int NU = 3, bool LEAN = false> constexpr int cx2_waves_per_simd() {
+  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP, LEAN>(), by_thr = 2048 / CX_WG;
   int wgs = by_lds < by_thr ? by_lds : by_thr;
   if (NU >= 4 && wgs > 3) wgs = 3;                        // four chunks per lane in flight need 80 VGPRs
   if (wgs * CX_WG / 256 > EPI_CX_WPS) wgs = EPI_CX_WPS * 256 / CX_WG;
   return (wgs < 1 ? 1 : wgs) * CX_WG / 256;
 }
 
-#define CX2_SHARED(T, NP)                                                                                        \
-  __shared__ __attribute__((aligned(16))) unsigned long long s_u8[Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR]; \
-  __shared__ __attribute__((aligned(16))) uint32_t s_wide[Cx2Lds<T, NP>::N_WIDE];                                \
-  __shared__ __attribute__((aligned(16))) uint32_t s_cov[Cx2Lds<T, NP>::N_COV];                                  \
-  static_assert((Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) * 8 >= 4 * T + 64, "the candidate lists and the scan scratch reuse the u8 arrays"); \
-  uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_u8) + T;   /* (dead until the last fold is done) */             \
-  (void)s_scan;                                                                                                   \
-  Cx2Lds<T, NP> L;                                                                                               \
-  L.narrow = s_u8; L.corr = s_u8 + Cx2Lds<T, NP>::N_NARROW; L.wide = s_wide; L.cov = s_cov;
+// LDS of a tile workgroup.  The emit phase's candidate lists (4 T bytes) and scan scratch reuse arrays that are dead by
+// then: the u8 counters and `corr` (general kernel), or `corr` and the small `wide` stub (LEAN: the counters are read).
+#define CX2_SHARED(T, NP, LEAN)                                                                                  \
+  using LdsT = Cx2Lds<T, NP, LEAN>;                                                                              \
+  __shared__ __attribute__((aligned(16))) unsigned long long s_u8[LdsT::N_NARROW + LdsT::N_CORR];                \
+  __shared__ __attribute__((aligned(16))) uint32_t s_wide[LdsT::N_WIDE];                                         \
+  __shared__ __attribute__((aligned(16))) uint32_t s_cov[LdsT::N_COV];                                           \
+  static_assert((LdsT::N_NARROW + LdsT::N_CORR) * 8 >= 4 * T + 64 && LdsT::N_CORR * 8 >= 4 * T, "the candidate lists and the scan scratch reuse dead arrays"); \
+  uint32_t *s_scan = LEAN ? s_wide : reinterpret_cast<uint32_t *>(s_u8) + T;                                      \
+  uint16_t *s_list = reinterpret_cast<uint16_t *>(LEAN ? s_u8 + LdsT::N_NARROW : s_u8);                          \
+  (void)s_scan; (void)s_list;                                                                                     \
+  LdsT L;                                                                                                         \
+  L.narrow = s_u8; L.corr = s_u8 + LdsT::N_NARROW; L.wide = s_wide; L.cov = s_cov;
 
-template <int T, int NP>
-__device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP> &L) {
+template <int T, int NP, bool LEAN>
+__device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP, LEAN> &L) {
+  using LdsT = Cx2Lds<T, NP, LEAN>;
   uint4 *z = reinterpret_cast<uint4 *>(L.narrow);
-  for (int i = threadIdx.x; i < (Cx2Lds<T, NP>::N_NARROW + Cx2Lds<T, NP>::N_CORR) / 2; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
-  uint4 *y = reinterpret_cast<uint4 *>(L.wide);
-  for (int i = threadIdx.x; i < Cx2Lds<T, NP>::N_WIDE / 4; i += CX_WG) y[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < (LdsT::N_NARROW + LdsT::N_CORR) / 2; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  if constexpr (!LEAN) {
+    uint4 *y = reinterpret_cast<uint4 *>(L.wide);
+    for (int i = threadIdx.x; i < LdsT::N_WIDE / 4; i += CX_WG) y[i] = make_uint4(0, 0, 0, 0);
+  }
   uint4 *x = reinterpret_cast<uint4 *>(L.cov);
-  for (int i = threadIdx.x; i < Cx2Lds<T, NP>::N_COV / 4; i += CX_WG) x[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < LdsT::N_COV / 4; i += CX_WG) x[i] = make_uint4(0, 0, 0, 0);
 }
 
 // rows [row_lo, row_hi) of a tile, folded every CX_FLUSH_ROWS rows; leaves everything in `wide` and `cov`
-template <int T, int G, int NU, int NP, bool FUSED>
-__device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP> &L) {
-  for (int b0 = row_lo; b0 < row_hi; b0 += CX_FLUSH_ROWS) {
-    if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP>(L); __syncthreads(); }
-    cx2_rows<T, G, NU, NP, FUSED>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
+__device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP, LEAN> &L) {
+  if constexpr (LEAN) {
+    cx2_rows<T, G, NU, NP, FUSED>(a, td, row_lo, row_hi, L);
+  } else {
+    for (int b0 = row_lo; b0 < row_hi; b0 += CX_FLUSH_ROWS) {
+      if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP, LEAN>(L); __syncthreads(); }
+      cx2_rows<T, G, NU, NP, FUSED>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
+    }
   }
   __syncthreads();
-  cx2_flush<T, NP>(L);
+  cx2_flush<T, NP, LEAN>(L);
   __syncthreads();
 }
 
-template <int T, int G, int NU, int NP, bool FUSED>
-__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_tiles(Cx2Args a, int ntiles) {
-  CX2_SHARED(T, NP)
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
+__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU, LEAN>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+  CX2_SHARED(T, NP, LEAN)
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
-  cx2_clear<T, NP>(L);
+  cx2_clear<T, NP, LEAN>(L);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
     if (threadIdx.x == 0) {
@@ -698,35 +744,42 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx
     return;
   }
   __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED>(a, td, td.row_lo, td.row_hi, L);
+  cx2_accumulate<T, G, NU, NP, FUSED, LEAN>(a, td, td.row_lo, td.row_hi, L);
   if (td.slot >= 0) {
     // shared with another rank: hand the raw sums over
-    cx2_dump_slab<T, NP>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
+    cx2_dump_slab<T, NP, LEAN>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
   if (EPI_CX_ABLATE & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   // (a list-free emit -- every thread ruling on its own 8 cells, two barriers instead of four -- measured 1-2 % slower)
   cx2_prefix<T>(L.cov, s_scan);
-  CxSrcLds<T, NP> src;
-  src.wide = L.wide; src.cov = L.cov;
-  cx2_emit<T, NP>(a, tile, src, s_scan, reinterpret_cast<uint16_t *>(s_u8));
+  if constexpr (LEAN) {
+    static_assert(NP == 1, "the u8 counters serve single-context reports");
+    CxSrcU8<T> src;
+    src.narrow = reinterpret_cast<const uint32_t *>(L.narrow); src.cov = L.cov;
+    cx2_emit<T, NP>(a, tile, src, s_scan, s_list);
+  } else {
+    CxSrcLds<T, NP> src;
+    src.wide = L.wide; src.cov = L.cov;
+    cx2_emit<T, NP>(a, tile, src, s_scan, s_list);
+  }
 }
 
 // One chunk of the candidate rows of one heavy tile: LDS sums as usual, then added into the tile's slab in HBM (or
 // straight into its shared slab slot when other ranks contribute too).
 template <int T, int G, int NU, int NP, bool FUSED>
 __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_heavy(Cx2Args a) {
-  CX2_SHARED(T, NP)
+  CX2_SHARED(T, NP, false)
   const int tile = (int)a.heavy_list[blockIdx.y];
   const Tile td = a.tiles[tile];
   const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
   if (lo >= td.row_hi) return;
   const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
-  cx2_clear<T, NP>(L);
+  cx2_clear<T, NP, false>(L);
   __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED>(a, td, lo, hi, L);
-  cx2_dump_slab<T, NP>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+  cx2_accumulate<T, G, NU, NP, FUSED, false>(a, td, lo, hi, L);
+  cx2_dump_slab<T, NP, false>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
                                         : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
 }
 
@@ -849,7 +902,9 @@ __device__ __forceinline__ void cxp_dump_slab(const Cx2Args &a, const uint32_t *
   const CxSrcPk src = cxp_source(a, cnt);
   for (int i = threadIdx.x; i < 2 * T; i += CX_WG) {
     const int sd = i / T, pos = i % T;
-    for (int p = 0; p < np; p++) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) {                          // (static plane index: the table stays in registers)
+      if (p >= np) break;
       uint32_t n, M;
       src.pair(sd, p, pos, &n, &M);
       if (n) atomicAdd(dst + (2 * (sd * np + p)) * T + pos, n);
@@ -968,17 +1023,23 @@ static int pick_cx_shape(int32_t max_len, int T, bool fused) {
 }
 static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3; }
 
+template <int T, int NU, int NP, bool FUSED, bool LEAN>
+static void launch_cx_tiles(int g, int nt, hipStream_t s, const Cx2Args &a) {
+  const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
+  switch (g) {
+    case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); } break;
+    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+  }
+}
+
 template <int T, int NU, int NP, bool FUSED>
-static void launch_cx_g(bool heavy, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+static void launch_cx_g(bool heavy, bool lean, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   if (!heavy) {
-    const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
-    switch (g) {
-      case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); } break;
-      case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-      default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NU, NP, FUSED>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-    }
+    if (lean) launch_cx_tiles<T, NU, NP, FUSED, true>(g, nt, s, a);
+    else launch_cx_tiles<T, NU, NP, FUSED, false>(g, nt, s, a);
     return;
   }
   switch (g) {
@@ -1021,12 +1082,12 @@ static void launch_cxp(bool heavy, int np, int g, int nt, dim3 grid, hipStream_t
   else hipLaunchKernelGGL((k_cx_emit_heavy<CXP_T, 3>), dim3(grid.y), dim3(CX_WG), 0, s, a);
 }
 
-static void launch_cx(bool heavy, int np, bool fused, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
+static void launch_cx(bool heavy, int np, bool fused, bool lean, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   const int g = shape >> 3;
   if (np > 1) { launch_cxp(heavy, np, g, nt, grid, s, a); return; }   // several contexts: one packed-pair atomic per base
   if (fused) {                                             // one context, 2048-position tiles
-    launch_cx_g<CX_T1, 3, 1, true>(heavy, g, nt, grid, s, a);
-  } else launch_cx_g<CX_T1, 3, 1, false>(heavy, g, nt, grid, s, a);
+    launch_cx_g<CX_T1, 3, 1, true>(heavy, lean, g, nt, grid, s, a);
+  } else launch_cx_g<CX_T1, 3, 1, false>(heavy, lean, g, nt, grid, s, a);
 }
 
 static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
@@ -1192,6 +1253,9 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   }
   const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused);   // lanes per row * 8 + chunks per lane
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
+  // u8 counters without folds when no position is covered by more than 255 rows (k_row_stats)
+  bool lean = np == 1 && st.deep == 0;
+  if (const char *env = getenv("EPIHIP_CX_LEAN")) { if (atoi(env) == 0) lean = false; }   // test hook: the general kernel
 
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
@@ -1233,7 +1297,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     }
     prof_begin("cx_tiles", s);
-    launch_cx(false, np, fused, grp, nt, dim3(1), s, a);
+    launch_cx(false, np, fused, lean, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
@@ -1247,7 +1311,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
       prof_begin("cx_heavy", s);
-      launch_cx(true, np, fused, grp, nt, dim3(nchunks, nheavy), s, a);
+      launch_cx(true, np, fused, lean, grp, nt, dim3(nchunks, nheavy), s, a);
       prof_end("cx_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));

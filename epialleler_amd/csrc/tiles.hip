@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
                                                     const int32_t *__restrict__ strand, const int64_t *__restrict__ off,
                                                     int64_t n, RowStats *__restrict__ st) {
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int len = 0, unsorted = 0, bad_strand = 0, bad_len = 0;
+  int len = 0, unsorted = 0, bad_strand = 0, bad_len = 0, deep = 0;
   if (x < n) {
     const int64_t l = off[x + 1] - off[x];
     const int32_t s0 = start[x];
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
       const int32_t r0 = rname[x - 1], r1 = rname[x];
       if (r1 < r0 || (r1 == r0 && s0 < start[x - 1])) unsorted = 1;
     }
+    // Rows covering a position p are consecutive-ish in the sorted order: if x is the first of them, all of them start
+    // before start[x] + len[x].  So when row x + 255 starts at or behind the end of row x (for every x), no position is
+    // covered by more than 255 rows, and u8 counters per position cannot overflow (cx_report.hip, LEAN).
+    if (len > 0 && x + 255 < n && rname[x + 255] == rname[x] && (int64_t)start[x + 255] < (int64_t)s0 + len) deep = 1;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
     unsorted |= __shfl_xor(unsorted, d, 64);
     bad_strand |= __shfl_xor(bad_strand, d, 64);
     bad_len |= __shfl_xor(bad_len, d, 64);
+    deep |= __shfl_xor(deep, d, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     // uniform-length input: after the first few waves the cached maximum already covers `len`
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
     if (unsorted) atomicOr(&st->unsorted, 1);
     if (bad_strand) atomicOr(&st->bad_strand, 1);
     if (bad_len) atomicOr(&st->bad_len, 1);
+    if (deep) atomicOr(&st->deep, 1);
   }
 }
 

@@ -148,6 +148,26 @@ def test_empty_and_degenerate(ea):
     check_all(ea, H.templates_from_xm(["++--", "-+-+"], [1, 3], [1, 2]))
 
 
+@pytest.mark.parametrize("depth", [254, 255, 256, 257, 300, 600])
+def test_u8_counter_limit(ea, depth):
+    """Single-context CX reports keep u8 counters per position and drop the u16 copy when no position is covered by
+    more than 255 rows (row x + 255 starts behind the end of row x): exactly at, just above and far above that depth,
+    with rows piled on one position, staggered by one base, and pile-ups next to ordinary coverage."""
+    rng = np.random.default_rng(depth)
+    xm1 = "Z" * 7 + "z" + "." * 20 + "ZxZ" + "h" * 5
+    piled = H.templates_from_xm([xm1] * depth, [100] * depth, [1 + (i % 2) for i in range(depth)])
+    check_all(ea, piled, mhl=False, contexts=("CG",))
+    same_strand = H.templates_from_xm([xm1] * depth, [100] * depth, [1] * depth)
+    check_all(ea, same_strand, mhl=False, contexts=("CG", "CHG"))
+    staggered = H.templates_from_xm([xm1] * depth, [5 + i // 8 for i in range(depth)], [1] * depth)   # 8 rows per start, ~36 long
+    check_all(ea, staggered, mhl=False, contexts=("CG",))
+    letters = np.frombuffer(b"....hhxzZZ.-", np.uint8)                 # a pile-up in the middle of ordinary coverage
+    xs = ["".join(map(chr, rng.choice(letters, int(rng.integers(20, 90))))) for _ in range(400)] + [xm1] * depth
+    starts = [int(v) for v in rng.integers(1, 5000, 400)] + [2500] * depth
+    strands = [int(v) for v in rng.integers(1, 3, 400 + depth)]
+    check_all(ea, H.templates_from_xm(xs, starts, strands), mhl=False, contexts=("CG",))
+
+
 def test_ragged_random(ea):
     rng = np.random.default_rng(11)
     for n, mx, span in ((1, 50, 100), (7, 40, 60), (300, 400, 3000), (2000, 700, 20000), (500, 33, 400)):

@@ -20,6 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot
     {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
+    {"EPIHIP_CX_LEAN": "0"},                                             # single-context CX reports: the general kernel (u16 copy of the
+                                                                         # u8 counters, folds) also where no position is deeper than 255 rows
+    {"EPIHIP_CX_LEAN": "0", "EPIHIP_HEAVY_ROWS": "100", "EPIHIP_CX_SLOT": "3"},
     {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL (fused kernel): nearly every tile outgrows its pool slot
     {"EPIHIP_MHL_SLOT": "0"},
     {"EPIHIP_HEAVY_ROWS": "40"},                                         # fused lMHL kernel gives up on tiles with > 40 rows: two-kernel path
