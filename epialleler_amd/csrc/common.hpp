@@ -124,6 +124,8 @@ struct epi_batch {
   int last_kind = 0;        // 0 none, 1 cx, 2 mhl
   int64_t last_nrow = 0;
   int32_t last_ntiles = 0;
+  int32_t tile_hint_T[4] = {0, 0, 0, 0};    // tile counts of this (immutable) batch by tile size, as found by earlier calls
+  int32_t tile_hint_nt[4] = {0, 0, 0, 0};
   int32_t last_tile = 0;    // tile size of the last CX report
 
   // multi-GPU shared tiles
@@ -154,7 +156,9 @@ int launch_row_stats(epi_batch *b, hipStream_t s);
 // host copy of the statistics (waits for the kernel whatever stream it was queued on); no validation
 int fetch_row_stats(epi_batch *b, hipStream_t s);
 // row statistics (validated: errors for bad offsets/strands/unsorted rows) + tile table; one host sync
-int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out);
+// `hinted` (may be null): the caller accepts a tile count remembered from an earlier call on this batch and tile size
+// (no host round trip in the middle of the index build) and verifies it against misc[0] at its own synchronisation.
+int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out, bool *hinted = nullptr);
 
 // profiling
 void prof_begin(const char *name, hipStream_t s);

@@ -1186,7 +1186,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   const int T = cx_tile_for(np);
   RowStats st;
   int32_t nt = 0;
-  EPI_TRY(build_tiles(b, s, T, &st, &nt));
+  bool nt_hinted = false;
+  EPI_TRY(build_tiles(b, s, T, &st, &nt, &nt_hinted));
   b->last_ntiles = nt;
   b->last_tile = T;
   a.fill4 = 0x0C0C0C0Cu;                                   // '.': never a call, never skipped, also when lower-cased
@@ -1302,8 +1303,13 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    uint32_t host[8];
-    EPI_TRY(read_scalars(b, s, cursor, 32, host));         // misc[1..8]
+    uint32_t host9[9];
+    EPI_TRY(read_scalars(b, s, cursor - 1, 36, host9));    // misc[0..8]
+    uint32_t *host = host9 + 1;
+    if (nt_hinted && host9[0] != (uint32_t)nt) {
+      for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
+      return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host9[0], nt);
+    }
     if (host[2] > 0) {
       // ultra-deep tiles were set aside: split each over ceil(rows/chunk) workgroups, reduce in HBM, emit, rescan
       const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;

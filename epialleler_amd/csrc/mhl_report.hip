@@ -60,7 +60,11 @@ __host__ __device__ __forceinline__ uint64_t nrS(uint64_t n) { return n < 2 ? n 
 // mhl_lookup[n] (:110-116) without the table; indices clamp at 65535 (the reference's table ends there)
 __device__ __forceinline__ uint64_t mhl_lut(uint32_t n, uint32_t H) {
   if (n > 65535u) n = 65535u;
-  return n < H ? nrS(n) : nrS(H);
+  const uint32_t k = n < H ? n : H;
+  // below 1024 the product fits 32 bits (three 64-bit multiplies and a 64-bit division by 6 otherwise: ~40 VALU);
+  // decided per wavefront, so short-read batches never execute the wide form
+  if (__builtin_expect(__ballot(k >= 1024u) != 0ull, 0)) return nrS(k);
+  return k < 2u ? (uint64_t)k : (uint64_t)((k * (k + 1u) * (k + 2u)) / 6u);
 }
 
 struct MhlRec { uint32_t first, last, m; };       // bytes [first,last] of the row; m = members of the stretch, 0 = counted run
@@ -1132,25 +1136,27 @@ __device__ __forceinline__ M mhlf_span_bits(const Chunk<M> &c, uint32_t enter, u
   return (M)(up & dn & nl) & ~c.K & c.V;
 }
 
-// calls fn(first bit, length, m) for every run of set bits (m as write_runs computes it)
+// calls fn(first bit, length, m) for every run of set bits (m as write_runs computes it).  The run and -- for stretches --
+// the segment between the surrounding cuts come from carry propagation (adding the lowest set bit to a mask flips the
+// bits above it up to the first gap) instead of count-zeros / shift / compare chains.
 template <int W, class M, class FN>
-__device__ __forceinline__ void mhlf_for_runs(M bits, bool stretch, const Chunk<M> &c, uint32_t enter, uint32_t cont, FN fn) {
+__device__ __forceinline__ void mhlf_for_runs(M bits_, bool stretch, const Chunk<M> &c, uint32_t enter, uint32_t cont, FN fn) {
+  uint64_t bits = (uint64_t)bits_;
+  const uint64_t nl = (uint64_t)(~c.L & bm_below<M>(W)), rnl = __brevll(nl);  // non-cut bytes (and bit-reversed)
   while (bits) {
-    const int f = bm_ctz(bits);
-    const M t = ~(bits >> f);
-    const int e = t ? bm_ctz(t) : (int)(8 * sizeof(M)) - f;    // run length
+    const uint64_t low = bits & (0ull - bits);
+    const uint64_t run = ((bits + low) ^ bits) & bits;                           // the maximal run starting at `low`
+    const int f = bm_ctz(low), e = __popcll(run);
     uint32_t m = 0;
     if (stretch) {
-      const M lc = c.L & bm_below<M>(f);
-      const int a = lc ? bm_msb(lc) + 1 : 0;                   // segment = bits [a, b) between the surrounding cuts
-      const int end = f + e;
-      const M hc = end < W ? (c.L >> end) : (M)0;
-      const int b = hc ? end + bm_ctz(hc) : W;
-      const M segmask = bm_below<M>(b) & ~bm_below<M>(a);
-      m = (a == 0 ? enter : 0u) + (uint32_t)bm_popc(c.U & segmask) + (b == W ? cont : 0u);
+      // the run lies inside one segment (span bytes are never cuts): fill from its lowest bit up and down to the cuts
+      const uint64_t up = mhlf_fill_up(low, nl);
+      const uint64_t dn = __brevll(mhlf_fill_up(__brevll(low), rnl));
+      const uint64_t seg = up | dn;
+      m = ((seg & 1ull) ? enter : 0u) + (uint32_t)__popcll((uint64_t)c.U & seg) + (((seg >> (W - 1)) & 1ull) ? cont : 0u);
     }
     fn(f, e, m);
-    bits &= ~(bm_below<M>(e) << f);
+    bits ^= run;
   }
 }
 
@@ -1253,17 +1259,18 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
           mhlf_interval(dd, P0 + f, P0 + f + e, sh);
         });
       }
-      // calls of the context: u8 counters, one ds_add_u32 per dword that holds any (the nibble of the in-context plane
-      // spread to four bytes by one multiplication)
+      // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any (a nibble of the in-context
+      // plane is spread to four bytes by one multiplication)
       uint32_t *n8 = s_n8 + sidx * Q + (P0 >> 2);
       const uint64_t N = (uint64_t)(c.U | c.L);
       uint32_t fl = 0;
 #pragma unroll
-      for (int d = 0; d < 4 * C; d++) {
-        const uint32_t nib = (uint32_t)(N >> (4 * d)) & 15u;
-        const uint32_t nb = (nib * 0x00204081u) & 0x01010101u;
-        fl |= f8[d];
-        if (nb != 0u && (uint32_t)((P0 >> 2) + d) < (uint32_t)Q) atomicAdd(n8 + d, nb);
+      for (int e = 0; e < 2 * C; e++) {                                      // eight positions (two dwords of xm) per ds_add_u64
+        const uint32_t by = (uint32_t)(N >> (8 * e)) & 255u;
+        const uint32_t lo = ((by & 15u) * 0x00204081u) & 0x01010101u, hi = ((by >> 4) * 0x00204081u) & 0x01010101u;
+        fl |= f8[2 * e] | f8[2 * e + 1];
+        if (by != 0u && (uint32_t)((P0 >> 2) + 2 * e) < (uint32_t)Q)        // (P0 is a multiple of 16: the pair is aligned, and in or out together)
+          atomicAdd(reinterpret_cast<unsigned long long *>(n8 + 2 * e), (unsigned long long)lo | ((unsigned long long)hi << 32));
       }
       // rare bytes: skipped (coverage -1 over their runs), nibble 9 (coverage +1), stray nibbles 3 / 4 / 8 (+1 on the sum
       // their counter is).  Kept compact (bit planes + loops over set bits): unrolled per byte it was most of the kernel's

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
                                                            int64_t n, int32_t lmax, int32_t sh, uint32_t *__restrict__ bsum,
                                                            Tile *__restrict__ tiles, const int64_t *__restrict__ shared_keys,
                                                            int32_t nshared, int32_t *__restrict__ slot_tile,
-                                                           uint32_t *__restrict__ misc) {
+                                                           uint32_t *__restrict__ misc, int64_t cap) {
+  // (cap = entries of `tiles`: the count may be one remembered from an earlier call -- a batch that was changed since
+  //  must not write behind the table before the host notices)
   __shared__ uint32_t s_tot[TB_ITEMS][TB_THREADS / 64];
   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) {       // the report kernels' counters start at zero (saves three memsets)
     misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0;    // pool cursor, output rows, heavy tiles, largest heavy tile
@@ -163,12 +165,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
     const int64_t x = base + (int64_t)i * TB_THREADS;
     if (x >= n) continue;
     const uint32_t before = inc[i] - c[i] + s_tot[i][wave];      // tiles created by rows < x
-    for (int64_t t = rt[i].hi_a; t <= rt[i].hi_b; t++)            // tiles this row closes
-      tiles[(int64_t)before - 1 - (rt[i].bp - t)].row_hi = (int32_t)x;
+    for (int64_t t = rt[i].hi_a; t <= rt[i].hi_b; t++) {          // tiles this row closes
+      const int64_t j = (int64_t)before - 1 - (rt[i].bp - t);
+      if (j >= 0 && j < cap) tiles[j].row_hi = (int32_t)x;
+    }
     if (c[i]) {
       const int32_t r = rname[x];
       for (uint32_t k = 0; k < c[i]; k++) {                       // tiles this row creates: it IS their row_lo
         const int64_t t = rt[i].lo + k;                           // (the first row with start >= pos0 - lmax + 1)
+        if ((int64_t)before + k >= cap) break;
         Tile *td = tiles + before + k;
         td->pos0 = t * T - kPosBias;
         td->rname = r;
@@ -185,8 +190,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
     }
     if (x == n - 1) {                                             // the end of the table closes what the last row reaches
       const int64_t sx = tile_of(start[x], sh);
-      for (int64_t t = sx; t <= rt[i].b; t++)
-        tiles[(int64_t)before + c[i] - 1 - (rt[i].b - t)].row_hi = (int32_t)n;
+      for (int64_t t = sx; t <= rt[i].b; t++) {
+        const int64_t j = (int64_t)before + c[i] - 1 - (rt[i].b - t);
+        if (j >= 0 && j < cap) tiles[j].row_hi = (int32_t)n;
+      }
     }
   }
 }
@@ -223,8 +230,9 @@ int fetch_row_stats(epi_batch *b, hipStream_t s) {
 
 // Validated row statistics (errors for bad offsets / strands / unsorted rows) + the tile table for tiles of T
 // positions.  One host synchronisation per call (the tile count); the statistics come back with the first one.
-int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *ntiles_out) {
+int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *ntiles_out, bool *hinted) {
   *ntiles_out = 0;
+  if (hinted) *hinted = false;
   memset(h, 0, sizeof(*h));
   if ((T & (T - 1)) != 0) return fail(EPI_ERR_ARG, "tile size must be a power of two");
   const int sh = log2_tile(T);
@@ -244,11 +252,23 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   EPI_TRY(b->scan_tmp.ensure((size_t)nb * 4));
   uint32_t *bsum = b->scan_tmp.as<uint32_t>();
   hipLaunchKernelGGL((k_tile_pass<false>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
-                     (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr, d_misc);
+                     (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr, d_misc, (int64_t)0);
   EPI_HIP(hipGetLastError());
   EPI_TRY(scan_block_sums_inplace(bsum, nb, d_misc, s));
+  // The tile count sizes the table and the grids.  It is a function of the batch's rows and T alone, so a count found
+  // by an earlier call stands in for the host round trip here; the caller checks it against misc[0] when it next
+  // synchronises anyway (a batch whose buffers were changed under us is reported there).
   uint32_t nt = 0;
-  EPI_TRY(read_scalars(b, s, d_misc, 4, &nt));
+  int slot = -1;
+  for (int i = 0; i < 4; i++) if (b->tile_hint_T[i] == T) slot = i;
+  if (hinted && slot >= 0) {
+    nt = (uint32_t)b->tile_hint_nt[slot];
+    *hinted = true;
+  } else {
+    EPI_TRY(read_scalars(b, s, d_misc, 4, &nt));
+    if (slot < 0) for (int i = 0; i < 4 && slot < 0; i++) if (b->tile_hint_T[i] == 0) slot = i;
+    if (slot >= 0 && nt <= 0x7FFFFFF0u) { b->tile_hint_T[slot] = T; b->tile_hint_nt[slot] = (int32_t)nt; }
+  }
   if (nt > 0x7FFFFFF0u) return fail(EPI_ERR_ARG, "too many tiles (%u)", nt);
   EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
   const int32_t nshared = (int32_t)b->shared_keys.size();
@@ -257,7 +277,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
     EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
   }
   hipLaunchKernelGGL((k_tile_pass<true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
-                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>(), d_misc);
+                     b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>(), d_misc, (int64_t)nt);
   EPI_HIP(hipGetLastError());
   *ntiles_out = (int32_t)nt;
   return EPI_OK;

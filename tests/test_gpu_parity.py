@@ -168,6 +168,35 @@ def test_u8_counter_limit(ea, depth):
     check_all(ea, H.templates_from_xm(xs, starts, strands), mhl=False, contexts=("CG",))
 
 
+def test_batch_changed_under_a_remembered_tile_count(ea):
+    """The tile count of a batch is remembered between reports (it saves a host round trip inside the index build) and
+    verified at the next synchronisation: a batch whose device buffers were rewritten in place is reported, not
+    mis-tiled, and the call after that works on the new contents."""
+    from epialleler_amd._lib import EpihipError
+    rng = np.random.default_rng(5)
+    import torch
+    t = synth_np.random_templates(rng, 3000, 30, 120, 1, 20000)
+    nb = int(t["off"][-1])
+    xm = torch.zeros((nb + 15) // 16 * 16, dtype=torch.uint8, device="cuda:0")
+    xm[:nb] = torch.from_numpy(t["xm"]).cuda()
+    bam = ea.ProcessedBam.from_device(xm, nb, torch.from_numpy(t["off"]).cuda(), torch.from_numpy(t["rname"]).cuda(),
+                                      torch.from_numpy(t["strand"]).cuda(), torch.from_numpy(t["start"]).cuda())
+    try:
+        for _ in range(2):                                   # the second call runs on the remembered count
+            H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, None, "Z")),
+                                   orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], None, "Z"))
+        bam.dev["start"][1500:] += 100000                    # still sorted; far more tiles than before
+        t2 = dict(t)
+        t2["start"] = t["start"].copy()
+        t2["start"][1500:] += 100000
+        with pytest.raises(EpihipError, match="changed"):
+            ea.rcpp_cx_report(bam, None, "Z")
+        H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, None, "Z")),
+                               orc.cx_report(t2["xm"], t2["off"], t2["rname"], t2["strand"], t2["start"], None, "Z"))
+    finally:
+        bam.close()
+
+
 def test_ragged_random(ea):
     rng = np.random.default_rng(11)
     for n, mx, span in ((1, 50, 100), (7, 40, 60), (300, 400, 3000), (2000, 700, 20000), (500, 33, 400)):
