@@ -126,6 +126,8 @@ struct epi_batch {
   int32_t last_ntiles = 0;
   int32_t tile_hint_T[4] = {0, 0, 0, 0};    // tile counts of this (immutable) batch by tile size, as found by earlier calls
   int32_t tile_hint_nt[4] = {0, 0, 0, 0};
+  int32_t tile_hint_lmax[4] = {0, 0, 0, 0};
+  epi::DevBuf tile_bsum[4];                  // ... and the scanned per-block tile counts of the index build
   int32_t last_tile = 0;    // tile size of the last CX report
 
   // multi-GPU shared tiles

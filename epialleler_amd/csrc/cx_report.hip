@@ -1201,7 +1201,10 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       a.pass_out = d_pass_out;
       // decisions from a table over the possible class totals (filled on the device with the reference's own
       // expressions); kept while the thresholds do not change
-      const bool same = b->thr_tab_len == st.max_len && memcmp(&b->thr_tab_prm, &thr->prm, sizeof(ThrParams)) == 0;
+      // (field by field: the caller's struct may carry padding; doubles bitwise, so that a NaN threshold compares equal to itself)
+      const bool same = b->thr_tab_len == st.max_len && b->thr_tab_prm.min_n_ctx == thr->prm.min_n_ctx &&
+                        memcmp(&b->thr_tab_prm.min_ctx_meth_frac, &thr->prm.min_ctx_meth_frac, sizeof(double)) == 0 &&
+                        memcmp(&b->thr_tab_prm.max_ooctx_meth_frac, &thr->prm.max_ooctx_meth_frac, sizeof(double)) == 0;
       if (!same) {
         EPI_TRY(b->thr_tab.ensure((size_t)(st.max_len + 1) * 4));
         hipLaunchKernelGGL(k_thr_table, dim3((unsigned)(st.max_len / 256 + 1)), dim3(256), 0, s, thr->prm, st.max_len, b->thr_tab.as<uint32_t>());

@@ -96,7 +96,11 @@ __device__ __forceinline__ RowTiles row_tiles(const int32_t *start, const int32_
 // (k_scan_bsums) pass B (FILL = true) recomputes the counts, scans them inside the block and writes the tiles.
 constexpr int TB_THREADS = 256, TB_ITEMS = 8, TB_ROWS = TB_THREADS * TB_ITEMS;
 
-template <bool FILL>
+// VERIFY (with FILL): `bsum` is the scanned block-sum array remembered from an earlier call on this batch and tile
+// size (the count pass, the scan and the host round trip are skipped); every block checks its own total against it and
+// the table's capacity `cap` is the remembered tile count.  misc[0] (zeroed before the launch) ends up as that count,
+// or as 0xFFFFFFFF when any block disagrees -- the rows were changed under the batch -- which the caller reports.
+template <bool FILL, bool VERIFY = false>
 __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                            int64_t n, int32_t lmax, int32_t sh, uint32_t *__restrict__ bsum,
                                                            Tile *__restrict__ tiles, const int64_t *__restrict__ shared_keys,
@@ -157,6 +161,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
     const uint32_t t = lane < NT ? flat[lane] : 0u;
     const uint32_t inc2 = wave_scan_u32(t);
     if (lane < NT) flat[lane] = bsum[blockIdx.x] + inc2 - t;   // + the tiles created before this block (already scanned)
+    if constexpr (VERIFY) {
+      if (lane == 63) {
+        const uint32_t expect = (blockIdx.x + 1 < gridDim.x ? bsum[blockIdx.x + 1] : (uint32_t)cap) - bsum[blockIdx.x];
+        if (inc2 != expect) atomicMax(misc, 0xFFFFFFFFu);
+        else if (blockIdx.x == 0) atomicMax(misc, (uint32_t)cap);
+      }
+    }
   }
   __syncthreads();
   const int64_t T = 1LL << sh;
@@ -249,25 +260,43 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
                                   "(src/rcpp_cx_report.cpp:19)");
   const int32_t lmax = h->max_len > 0 ? h->max_len : 1;
   const int64_t nb = (b->n + TB_ROWS - 1) / TB_ROWS;
+  EPI_TRY(check_grid(nb, TB_THREADS, "tile index"));
+  int slot = -1;
+  for (int i = 0; i < 4; i++) if (b->tile_hint_T[i] == T) slot = i;
+  if (hinted && slot >= 0 && b->tile_hint_lmax[slot] == lmax) {
+    // The tile count and the per-block offsets are functions of the batch's rows and T alone: with those of an earlier
+    // call the table is allocated up front and filled by ONE pass that verifies them block by block; the caller
+    // compares misc[0] with the count when it next synchronises anyway.
+    const uint32_t nt = (uint32_t)b->tile_hint_nt[slot];
+    EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
+    const int32_t nshared = (int32_t)b->shared_keys.size();
+    if (nshared > 0) {
+      EPI_TRY(b->d_slot_tile.ensure((size_t)nshared * 4));
+      EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
+    }
+    EPI_HIP(hipMemsetAsync(d_misc, 0, 4, s));
+    hipLaunchKernelGGL((k_tile_pass<true, true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh,
+                       b->tile_bsum[slot].as<uint32_t>(), b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared,
+                       b->d_slot_tile.as<int32_t>(), d_misc, (int64_t)nt);
+    EPI_HIP(hipGetLastError());
+    *hinted = true;
+    *ntiles_out = (int32_t)nt;
+    return EPI_OK;
+  }
   EPI_TRY(b->scan_tmp.ensure((size_t)nb * 4));
   uint32_t *bsum = b->scan_tmp.as<uint32_t>();
   hipLaunchKernelGGL((k_tile_pass<false>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
                      (Tile *)nullptr, (const int64_t *)nullptr, 0, (int32_t *)nullptr, d_misc, (int64_t)0);
   EPI_HIP(hipGetLastError());
   EPI_TRY(scan_block_sums_inplace(bsum, nb, d_misc, s));
-  // The tile count sizes the table and the grids.  It is a function of the batch's rows and T alone, so a count found
-  // by an earlier call stands in for the host round trip here; the caller checks it against misc[0] when it next
-  // synchronises anyway (a batch whose buffers were changed under us is reported there).
   uint32_t nt = 0;
-  int slot = -1;
-  for (int i = 0; i < 4; i++) if (b->tile_hint_T[i] == T) slot = i;
-  if (hinted && slot >= 0) {
-    nt = (uint32_t)b->tile_hint_nt[slot];
-    *hinted = true;
-  } else {
-    EPI_TRY(read_scalars(b, s, d_misc, 4, &nt));
-    if (slot < 0) for (int i = 0; i < 4 && slot < 0; i++) if (b->tile_hint_T[i] == 0) slot = i;
-    if (slot >= 0 && nt <= 0x7FFFFFF0u) { b->tile_hint_T[slot] = T; b->tile_hint_nt[slot] = (int32_t)nt; }
+  EPI_TRY(read_scalars(b, s, d_misc, 4, &nt));
+  if (nt <= 0x7FFFFFF0u) {                                 // remember count and block offsets for the one-pass path above
+    for (int i = 0; i < 4 && slot < 0; i++) if (b->tile_hint_T[i] == 0) slot = i;
+    if (slot >= 0 && b->tile_bsum[slot].ensure((size_t)nb * 4) == EPI_OK &&
+        hipMemcpyAsync(b->tile_bsum[slot].p, bsum, (size_t)nb * 4, hipMemcpyDeviceToDevice, s) == hipSuccess) {
+      b->tile_hint_T[slot] = T; b->tile_hint_nt[slot] = (int32_t)nt; b->tile_hint_lmax[slot] = lmax;
+    }
   }
   if (nt > 0x7FFFFFF0u) return fail(EPI_ERR_ARG, "too many tiles (%u)", nt);
   EPI_TRY(b->tiles.ensure((size_t)nt * sizeof(Tile)));
