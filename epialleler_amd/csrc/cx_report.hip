@@ -269,13 +269,19 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
 #pragma unroll
     for (int d = 0; d < 4; d++) { asm("" : "+v"(mf[d])); asm("" : "+v"(ml[d])); }    // (once per visit, not per use)
 #pragma unroll
+    for (int d = 0; d < 4; d++) w[0][d] = (w[0][d] & mf[d]) | (a.fill4 & ~mf[d]);
+    // rows of similar length have their last chunk at the same u: the other chunks of the wavefront skip the masking
+    // (a wave-uniform branch; the integer VALU these kernels are made of is what bounds them)
+#pragma unroll
     for (int u = 0; u < NU; u++) {
       const bool last = cb + u * G == g.clast;
+      if (__ballot(last) != 0ull) {
+        const uint32_t keep = last ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
-        uint32_t m = last ? ml[d] : 0xFFFFFFFFu;
-        if (u == 0) m &= mf[d];
-        w[u][d] = (w[u][d] & m) | (a.fill4 & ~m);
+        for (int d = 0; d < 4; d++) {
+          const uint32_t m = ml[d] | keep;
+          w[u][d] = (w[u][d] & m) | (a.fill4 & ~m);
+        }
       }
     }
   }
