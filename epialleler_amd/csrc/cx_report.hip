@@ -377,9 +377,9 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
 
 // Rows [row_lo, row_hi) of the tile into the u8 counters and the coverage array.  G lanes own a row (64/G rows per
 // wavefront step); the next step's row columns are fetched while the current row's bytes are in flight.
-template <int T, int G, int NU, int NP, bool FUSED, class LT>
+template <int T, int G, int NU, int NP, bool FUSED, int WG, class LT>
 __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const LT &L) {
-  constexpr int R = 64 / G, NW = CX_WG / 64, C = T / CX_CH;
+  constexpr int R = 64 / G, NW = WG / 64, C = T / CX_CH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   Tile tb = td;
@@ -428,11 +428,11 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
 }
 
 // u8 counters -> u16 pairs, skipped / doubled codes -> coverage difference array.  Every cell has one owner thread.
-template <int T, int NP, bool LEAN>
+template <int T, int NP, bool LEAN, int WG>
 __device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
   constexpr int Q = T / 4;
   if constexpr (!LEAN) {
-    for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
+    for (int i = threadIdx.x; i < 2 * NP * Q; i += WG) {
       const unsigned long long v = L.narrow[i];
       if (v == 0ull) continue;
       L.narrow[i] = 0ull;
@@ -447,7 +447,7 @@ __device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
       *wd = c;
     }
   }
-  for (int i = threadIdx.x; i < 2 * Q; i += CX_WG) {
+  for (int i = threadIdx.x; i < 2 * Q; i += WG) {
     const unsigned long long v = L.corr[i];
     if (v == 0ull) continue;
     L.corr[i] = 0ull;
@@ -519,10 +519,10 @@ template <int T, int NP> struct CxSrcSlab {
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { return cov[sd * T + pos]; }
 };
 
-// in-place inclusive prefix sum of arr[0..T) by the whole workgroup (T / CX_WG consecutive entries per thread)
-template <int T>
+// in-place inclusive prefix sum of arr[0..T) by the whole workgroup (T / WG consecutive entries per thread)
+template <int T, int WG = CX_WG>
 __device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
-  constexpr int PPT = T / CX_WG, NW = CX_WG / 64;
+  constexpr int PPT = T / WG, NW = WG / 64;
   static_assert(PPT >= 1 && PPT <= 8, "prefix layout");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t x[PPT];
@@ -545,9 +545,9 @@ __device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
 // them in blocks of 32: lanes 0-31 look at the '+' strand, lanes 32-63 at the '-' strand.  Pass 1 lists, in key order,
 // the cells with any call of a reported context (a row needs n_k > cov/2 >= 0); pass 2 reads the candidates densely,
 // one per lane, and applies the rule.  Ranks come from ballots and popcounts.
-template <int T, int NP, class SRC>
+template <int T, int NP, int WG = CX_WG, class SRC>
 __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &src, uint32_t *s_scan, uint16_t *s_list) {
-  constexpr int NW = CX_WG / 64, PW = T / NW, IT = PW / 32;
+  constexpr int NW = WG / 64, PW = T / NW, IT = PW / 32;
   static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");   // IT = 4 (T = 1024) or 8 (2048)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l5 = lane & 31, sd = lane >> 5;
@@ -628,12 +628,12 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
 
 // Adds a tile's (folded) LDS sums into its dense slab [16][T] in HBM (shared tiles, heavy tiles).  The coverage
 // array goes over un-summed: difference arrays add across work items and ranks like everything else.
-template <int T, int NP, bool LEAN>
+template <int T, int NP, bool LEAN, int WG>
 __device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int32_t *slab) {
   uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
   if constexpr (LEAN) {
     constexpr int Q = T / 4;
-    for (int i = threadIdx.x; i < 2 * NP * Q; i += CX_WG) {
+    for (int i = threadIdx.x; i < 2 * NP * Q; i += WG) {
       const unsigned long long v = L.narrow[i];
       if (v == 0ull) continue;
       const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -646,7 +646,7 @@ __device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int3
       }
     }
   } else {
-    for (int i = threadIdx.x; i < 2 * NP * T; i += CX_WG) {
+    for (int i = threadIdx.x; i < 2 * NP * T; i += WG) {
       const uint32_t v = L.wide[i];
       if (!v) continue;
       const int sp = i / T, p = i - sp * T;
@@ -654,7 +654,7 @@ __device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int3
       if (v >> 16) atomicAdd(dst + (2 * sp + 1) * T + p, v >> 16);
     }
   }
-  for (int p = threadIdx.x; p < T; p += CX_WG) {
+  for (int p = threadIdx.x; p < T; p += WG) {
     const uint32_t v = L.cov[p];
     if (!v) continue;
     const int32_t lo = (int32_t)(int16_t)(v & 0xFFFFu);                // both halves are signed before the prefix sum
@@ -680,12 +680,12 @@ template <int T, int NP, bool LEAN = false> constexpr int cx2_lds_bytes() {
 #ifndef EPI_CX_WPS
 #define EPI_CX_WPS 8
 #endif
-template <int T, int NP, int NU = 3, bool LEAN = false> constexpr int cx2_waves_per_simd() {
-  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP, LEAN>(), by_thr = 2048 / CX_WG;
+template <int T, int NP, int NU = 3, bool LEAN = false, int WG = CX_WG> constexpr int cx2_waves_per_simd() {
+  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP, LEAN>(), by_thr = 2048 / WG;
   int wgs = by_lds < by_thr ? by_lds : by_thr;
-  if (NU >= 4 && wgs > 3) wgs = 3;                        // four chunks per lane in flight need 80 VGPRs
-  if (wgs * CX_WG / 256 > EPI_CX_WPS) wgs = EPI_CX_WPS * 256 / CX_WG;
-  return (wgs < 1 ? 1 : wgs) * CX_WG / 256;
+  if (NU >= 4 && wgs * WG > 1536) wgs = 1536 / WG;        // five chunks per lane in flight need ~80 VGPRs: 6 waves per SIMD
+  if (wgs * WG / 256 > EPI_CX_WPS) wgs = EPI_CX_WPS * 256 / WG;
+  return (wgs < 1 ? 1 : wgs) * WG / 256;
 }
 
 // LDS of a tile workgroup.  The emit phase's candidate lists (4 T bytes) and scan scratch reuse arrays that are dead by
@@ -702,42 +702,47 @@ template <int T, int NP, int NU = 3, bool LEAN = false> constexpr int cx2_waves_
   LdsT L;                                                                                                         \
   L.narrow = s_u8; L.corr = s_u8 + LdsT::N_NARROW; L.wide = s_wide; L.cov = s_cov;
 
-template <int T, int NP, bool LEAN>
+template <int T, int NP, bool LEAN, int WG>
 __device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP, LEAN> &L) {
   using LdsT = Cx2Lds<T, NP, LEAN>;
   uint4 *z = reinterpret_cast<uint4 *>(L.narrow);
-  for (int i = threadIdx.x; i < (LdsT::N_NARROW + LdsT::N_CORR) / 2; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < (LdsT::N_NARROW + LdsT::N_CORR) / 2; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   if constexpr (!LEAN) {
     uint4 *y = reinterpret_cast<uint4 *>(L.wide);
-    for (int i = threadIdx.x; i < LdsT::N_WIDE / 4; i += CX_WG) y[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < LdsT::N_WIDE / 4; i += WG) y[i] = make_uint4(0, 0, 0, 0);
   }
   uint4 *x = reinterpret_cast<uint4 *>(L.cov);
-  for (int i = threadIdx.x; i < LdsT::N_COV / 4; i += CX_WG) x[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < LdsT::N_COV / 4; i += WG) x[i] = make_uint4(0, 0, 0, 0);
 }
 
 // rows [row_lo, row_hi) of a tile, folded every CX_FLUSH_ROWS rows; leaves everything in `wide` and `cov`
-template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, int WG>
 __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP, LEAN> &L) {
   if constexpr (LEAN) {
-    cx2_rows<T, G, NU, NP, FUSED>(a, td, row_lo, row_hi, L);
+    cx2_rows<T, G, NU, NP, FUSED, WG>(a, td, row_lo, row_hi, L);
   } else {
     for (int b0 = row_lo; b0 < row_hi; b0 += CX_FLUSH_ROWS) {
-      if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP, LEAN>(L); __syncthreads(); }
-      cx2_rows<T, G, NU, NP, FUSED>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
+      if (b0 > row_lo) { __syncthreads(); cx2_flush<T, NP, LEAN, WG>(L); __syncthreads(); }
+      cx2_rows<T, G, NU, NP, FUSED, WG>(a, td, b0, b0 + CX_FLUSH_ROWS < row_hi ? b0 + CX_FLUSH_ROWS : row_hi, L);
     }
   }
   __syncthreads();
-  cx2_flush<T, NP, LEAN>(L);
+  cx2_flush<T, NP, LEAN, WG>(L);
   __syncthreads();
 }
 
+// (the lean kernel runs 256-thread workgroups, six per CU: twice the row steps per wavefront and tile, so the fixed
+//  work per tile weighs half as much, and 80 VGPRs for the five-chunk lane shapes)
+template <bool LEAN> constexpr int cx2_wg() { return LEAN ? 256 : CX_WG; }
+
 template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
-__global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU, LEAN>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+__global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN, cx2_wg<LEAN>()>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+  constexpr int WG = cx2_wg<LEAN>();
   CX2_SHARED(T, NP, LEAN)
   const int tile = cx_tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
-  cx2_clear<T, NP, LEAN>(L);
+  cx2_clear<T, NP, LEAN, WG>(L);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
     if (threadIdx.x == 0) {
@@ -750,25 +755,25 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU, LEAN>())) voi
     return;
   }
   __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED, LEAN>(a, td, td.row_lo, td.row_hi, L);
+  cx2_accumulate<T, G, NU, NP, FUSED, LEAN, WG>(a, td, td.row_lo, td.row_hi, L);
   if (td.slot >= 0) {
     // shared with another rank: hand the raw sums over
-    cx2_dump_slab<T, NP, LEAN>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
+    cx2_dump_slab<T, NP, LEAN, WG>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
   if (EPI_CX_ABLATE & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
   // (a list-free emit -- every thread ruling on its own 8 cells, two barriers instead of four -- measured 1-2 % slower)
-  cx2_prefix<T>(L.cov, s_scan);
+  cx2_prefix<T, WG>(L.cov, s_scan);
   if constexpr (LEAN) {
     static_assert(NP == 1, "the u8 counters serve single-context reports");
     CxSrcU8<T> src;
     src.narrow = reinterpret_cast<const uint32_t *>(L.narrow); src.cov = L.cov;
-    cx2_emit<T, NP>(a, tile, src, s_scan, s_list);
+    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list);
   } else {
     CxSrcLds<T, NP> src;
     src.wide = L.wide; src.cov = L.cov;
-    cx2_emit<T, NP>(a, tile, src, s_scan, s_list);
+    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list);
   }
 }
 
@@ -782,10 +787,10 @@ __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx
   const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
   if (lo >= td.row_hi) return;
   const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
-  cx2_clear<T, NP, false>(L);
+  cx2_clear<T, NP, false, CX_WG>(L);
   __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED, false>(a, td, lo, hi, L);
-  cx2_dump_slab<T, NP, false>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+  cx2_accumulate<T, G, NU, NP, FUSED, false, CX_WG>(a, td, lo, hi, L);
+  cx2_dump_slab<T, NP, false, CX_WG>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
                                         : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
 }
 
@@ -1014,17 +1019,20 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
 static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : CXP_T; }
 
 // Lanes per row and 16-byte chunks per lane.  Whole rows (fused thresholding) must fit one visit of G * NU chunks
-// wherever they start inside their first chunk; slices of longer rows loop.  Returned as G * 8 + NU.
-static int pick_cx_shape(int32_t max_len, int T, bool fused) {
+// wherever they start inside their first chunk; so must the slice of a row inside a tile (at most T / 16 + 1 chunks).
+// The smallest G * NU that holds them wins: idle chunk slots cost the same VALU as used ones, and fewer lanes per row
+// are more rows per wavefront step (PE150: 20 chunks = 4 lanes x 5, against 8 x 3 = 24 slots).  Five chunks per lane
+// need ~80 VGPRs, which only the lean kernel's 256-thread workgroups have.  Returned as G * 8 + NU.
+static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
   const int64_t span = (fused ? (int64_t)max_len : (max_len < T ? max_len : T)) + (CX_CH - 1);
   const int chunks = (int)((span + CX_CH - 1) / CX_CH);
 #ifdef EPI_CX_FORCE_SHAPE                                  // timing builds only: (G, NU) = (EPI_CX_FORCE_SHAPE / 8, % 8)
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
-  // three chunks per lane: with five the kernel needs 80 VGPRs and still spills (0.7 GB of scratch traffic per launch on
-  // 10 M templates, 1.27x the algorithmic bytes through HBM) for the same speed
-  for (int g = fused ? 4 : 8; g < 64; g <<= 1)
+  for (int g = fused ? 4 : 8; g <= 64; g <<= 1) {
     if (g * 3 >= chunks) return g * 8 + 3;
+    if (lean && g * 5 >= chunks) return g * 8 + 5;
+  }
   return 64 * 8 + 3;
 }
 static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3; }
@@ -1033,11 +1041,11 @@ template <int T, int NU, int NP, bool FUSED, bool LEAN>
 static void launch_cx_tiles(int g, int nt, hipStream_t s, const Cx2Args &a) {
   const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); } break;
-    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
-    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NU, NP, FUSED, LEAN>), dim3(nb), dim3(CX_WG), 0, s, a, nt); break;
+    case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); } break;
+    case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
+    case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
+    case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
+    default: hipLaunchKernelGGL((k_cx_tiles<T, 64, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
   }
 }
 
@@ -1091,9 +1099,12 @@ static void launch_cxp(bool heavy, int np, int g, int nt, dim3 grid, hipStream_t
 static void launch_cx(bool heavy, int np, bool fused, bool lean, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   const int g = shape >> 3;
   if (np > 1) { launch_cxp(heavy, np, g, nt, grid, s, a); return; }   // several contexts: one packed-pair atomic per base
-  if (fused) {                                             // one context, 2048-position tiles
-    launch_cx_g<CX_T1, 3, 1, true>(heavy, lean, g, nt, grid, s, a);
-  } else launch_cx_g<CX_T1, 3, 1, false>(heavy, lean, g, nt, grid, s, a);
+  if (!heavy && lean && (shape & 7) == 5) {                // one context, 2048-position tiles, five chunks per lane
+    if (fused) launch_cx_tiles<CX_T1, 5, 1, true, true>(g, nt, s, a); else launch_cx_tiles<CX_T1, 5, 1, false, true>(g, nt, s, a);
+    return;
+  }
+  if (fused) launch_cx_g<CX_T1, 3, 1, true>(heavy, lean, g, nt, grid, s, a);
+  else launch_cx_g<CX_T1, 3, 1, false>(heavy, lean, g, nt, grid, s, a);
 }
 
 static void launch_cx_emit_slab(int np, int nshared, hipStream_t s, const Cx2Args &a, const int32_t *owned, const int32_t *slot_tile) {
@@ -1261,11 +1272,13 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     slot = 0;                                              // the slots do not fit in device memory: every tile through the
     ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
-  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused);   // lanes per row * 8 + chunks per lane
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
   // u8 counters without folds when no position is covered by more than 255 rows (k_row_stats)
   bool lean = np == 1 && st.deep == 0;
   if (const char *env = getenv("EPIHIP_CX_LEAN")) { if (atoi(env) == 0) lean = false; }   // test hook: the general kernel
+  // lanes per row * 8 + chunks per lane; the heavy-tile kernel is the general one (three chunks per lane)
+  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused, lean);
+  const int grp_heavy = np > 1 ? grp : pick_cx_shape(st.max_len, T, fused, false);
 
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
@@ -1326,7 +1339,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));
       prof_begin("cx_heavy", s);
-      launch_cx(true, np, fused, lean, grp, nt, dim3(nchunks, nheavy), s, a);
+      launch_cx(true, np, fused, lean, grp_heavy, nt, dim3(nchunks, nheavy), s, a);
       prof_end("cx_heavy", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
