@@ -115,6 +115,9 @@ struct epi_batch {
   uint32_t cx_last_ctx_of_plane = 0;
   epi::DevBuf pass_tmp;                        // pass flags when thresholding could not be fused and the caller wants none
   epi::DevBuf host_io;                         // device side of the host-pointer calls (pass flags / per-read beta)
+  epi::DevBuf mhl_keep_tab;                    // fused lMHL: passing out-of-context counts per total (k_mhl_keep_table)
+  int32_t mhl_keep_len = -1;
+  double mhl_keep_oo = 0.0;
   epi::DevBuf thr_tab;                         // fused thresholding: decision table for thr_tab_prm over totals 0..thr_tab_len
   int32_t thr_tab_len = -1;
   epi::ThrParams thr_tab_prm = {0, 0.0, 0.0};

@@ -1010,6 +1010,21 @@ __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ til
 // with other ranks make the caller fall back to the two-kernel path above.
 constexpr int MHLF_T = 1024, MHLF_WG = 512;
 
+// mhl_keep's out-of-context test without the fp64 division per row (17 double-precision instructions per wavefront
+// step): (double)m / (double)n > max_oo is monotone in m, so per n there is a count of passing m = 0 .. n; the table is
+// filled on the device with the reference's own expression (:178-179; 0/0 = NaN compares false: kept).
+__global__ __launch_bounds__(256) void k_mhl_keep_table(double max_oo, int32_t nmax, uint32_t *__restrict__ tab) {
+  const int32_t n = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (n > nmax) return;
+  int32_t lo = 0, hi = n + 1;                              // first m in [0, n] with frac > max_oo (n + 1: none)
+  while (lo < hi) {
+    const int32_t m = (lo + hi) >> 1;
+    const double frac = (double)(uint32_t)m / (double)(uint64_t)(uint32_t)n;
+    if (frac > max_oo) hi = m; else lo = m + 1;
+  }
+  tab[n] = (uint32_t)lo;
+}
+
 struct MhlFArgs {
   const uint8_t *xm;
   const int64_t *off;
@@ -1020,6 +1035,7 @@ struct MhlFArgs {
                                           // 32 doubled (nibble 9), 64 / 128 / 192 stray nibble 3 / 4 / 8 (their counter IS a sum, :190)
   int32_t hmin;
   double max_oo;
+  const uint32_t *keep_tab;               // [n] = passing out-of-context methylated counts for n out-of-context calls (k_mhl_keep_table)
   uint32_t H, ctx;                        // haplotype window clamp (:112), reported context code
   uint32_t *pool_key, *pool_cov;
   unsigned long long *pool_hs, *pool_nu, *pool_de;
@@ -1236,7 +1252,7 @@ __global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fu
     if (sub == G - 1) cont = 0u;
     const uint32_t h = grp_sum<G / 2>((uint32_t)bm_popc(c.U | c.L)), oo_m = grp_sum<G / 2>(c.oom), oo_u = grp_sum<G / 2>(c.oou);
     const uint32_t anyk = grp_or<G / 2>(c.K ? 1u : 0u);
-    const bool keep = valid && len > 0 && mhl_keep(h, oo_m, oo_u, a.hmin, a.max_oo);      // :176-179
+    const bool keep = valid && len > 0 && !((int)h < a.hmin) && oo_m < a.keep_tab[oo_m + oo_u];   // :176-179 (mhl_keep)
     if (keep) {
       const int sidx = sd - 1;
       const unsigned long long sh = mhl_lut(h, a.H);                         // S(h), :194
@@ -1557,6 +1573,17 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   a.tiles = b->tiles.as<Tile>();
   a.lut = make_mhlf_lut(ctx_mask);
   a.hmin = (int32_t)hmin; a.max_oo = max_oo; a.H = H; a.ctx = k;
+  {                                                        // decision table over 0 .. longest row; kept while max_oo does not change
+    const bool same = b->mhl_keep_len == st.max_len && memcmp(&b->mhl_keep_oo, &max_oo, sizeof(double)) == 0;
+    if (!same) {
+      EPI_TRY(b->mhl_keep_tab.ensure((size_t)(st.max_len + 1) * 4));
+      hipLaunchKernelGGL(k_mhl_keep_table, dim3((unsigned)(st.max_len / 256 + 1)), dim3(256), 0, s, max_oo, st.max_len, b->mhl_keep_tab.as<uint32_t>());
+      EPI_HIP(hipGetLastError());
+      b->mhl_keep_len = st.max_len;
+      b->mhl_keep_oo = max_oo;
+    }
+    a.keep_tab = b->mhl_keep_tab.as<uint32_t>();
+  }
   a.cursor = cursor;
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
