@@ -1,19 +1,20 @@
 // Host-side producer: BAM file -> sorted, packed SoA templates in pinned host memory.
 //
-// Replaces, for short-read XG/XM alignments, the reference's
+// Replaces the reference's
 //   rcpp_check_bam            src/rcpp_check_bam.cpp:19-60   + .checkBam  R/internal.R:75-128
-//   rcpp_read_bam_paired      src/rcpp_read_bam.cpp:19-192
+//   rcpp_read_bam_paired      src/rcpp_read_bam.cpp:19-192   (short-read XG/XM alignments)
 //   rcpp_read_bam_single      src/rcpp_read_bam.cpp:199-343
+//   rcpp_read_bam_mm_single   src/rcpp_read_bam.cpp:364-579  (long-read MM/ML alignments: pack_mm below)
 //   .readBam (templid, sort)  R/internal.R:154-199
 // without HTSlib: BGZF is a series of gzip members whose compressed size is in the
-// BC extra field (SAM spec 4.1), so the blocks are located without inflating and
-// inflated in parallel by worker threads straight into one buffer; BAM records have a
-// fixed layout (SAM spec 4.2).  The packed byte per reference position is
+// BC extra field (SAM spec 4.1), so the blocks are located without inflating (the file is
+// mmap-ed) and inflated in parallel by worker threads, window by window (a record or template
+// that straddles a window seam is carried over); BAM records have a fixed layout (SAM spec 4.2)
+// and are validated before use.  The packed byte per reference position is
 // (nt16 << 4) | ctx_to_idx(XM) (src/epialleleR.h:28-35), filler 0xFB (N,'-').
 // Output is what the GPU engine consumes: one contiguous byte stream in (rname,start)
 // order + offsets + int32 columns, allocated with hipHostMalloc when a HIP device is
 // usable (so it can be streamed to HBM with hipMemcpyAsync) and with malloc otherwise.
-// Long-read MM/ML alignments (rcpp_read_bam_mm_single) are not handled yet.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <stdio.h>

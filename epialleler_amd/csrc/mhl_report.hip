@@ -1712,7 +1712,8 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.tile_base = b->tile_base.as<uint32_t>();
   a.heavy_rows = 16384;
   if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
-  if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // packed u16 counters: a base adds at most 2
+  if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // k_mhl_tiles' packed u16 counters: a base adds at most 2 (the
+                                                           // CX kernels cap at 16384, cx_report.hip)
   const int heavy_rows_base = a.heavy_rows;
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
