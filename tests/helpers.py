@@ -174,5 +174,5 @@ def dirty_allocator(bam):
     """Leaves a freed block of non-zero int32s of the batch's row count in torch's caching allocator, so that the next
     torch.empty of that size (the `pass` column of cytosine_report_fused) starts out as garbage, not as zeros."""
     import torch
-    junk = torch.full((max(bam.n, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda:%d" % bam.device)
+    junk = torch.full((max(bam.n, 1),), 0x5A5A5A5A, dtype=torch.int32, device="cuda:%d" % (bam.device or 0))
     del junk
