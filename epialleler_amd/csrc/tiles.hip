@@ -70,18 +70,17 @@ struct RowTiles {
   int64_t hi_a, hi_b, bp; // closes tiles hi_a..hi_b (hi_b < hi_a: none); bp = predecessor's last reachable tile
 };
 
-__device__ __forceinline__ RowTiles row_tiles(const int32_t *start, const int32_t *rname, int64_t x, int32_t lmax, int32_t sh) {
+// (s, r) = start / rname of the row, (sp, rp) = of its predecessor (has_prev: the row is not the first of the table)
+__device__ __forceinline__ RowTiles row_tiles(int64_t s, int32_t r, int64_t sp, int32_t rp, bool has_prev, int32_t lmax, int32_t sh) {
   RowTiles rt;
-  const int64_t s = start[x];
   const int64_t sx = tile_of(s, sh);
   rt.b = tile_of(s + lmax - 1, sh);
   rt.lo = sx;
   rt.hi_a = 0; rt.hi_b = -1; rt.bp = 0;
-  if (x > 0) {
-    const int64_t sp = start[x - 1];
+  if (has_prev) {
     const int64_t tp = tile_of(sp, sh);
     rt.bp = tile_of(sp + lmax - 1, sh);
-    if (rname[x - 1] == rname[x]) {
+    if (rp == r) {
       if (rt.bp + 1 > rt.lo) rt.lo = rt.bp + 1;
       if (sx != tp) { rt.hi_a = tp; rt.hi_b = rt.bp < sx - 1 ? rt.bp : sx - 1; }
     } else {
@@ -94,7 +93,13 @@ __device__ __forceinline__ RowTiles row_tiles(const int32_t *start, const int32_
 // The tile table in two passes over (start, rname) with nothing stored per row in between: pass A (FILL = false)
 // reduces the per-row tile counts of a block of TB_ROWS rows to one number; after a single-block scan of those
 // (k_scan_bsums) pass B (FILL = true) recomputes the counts, scans them inside the block and writes the tiles.
+// A thread owns TB_ITEMS CONSECUTIVE rows: four 16-byte loads bring their columns, a row's predecessor is the
+// thread's previous row, and the scan in row order is a serial prefix inside the thread plus one wavefront scan of
+// the thread totals (the first version strided the rows over the threads: 32 scalar loads and eight wavefront scans
+// per thread, 51-67 us for 10 M rows against 30).
 constexpr int TB_THREADS = 256, TB_ITEMS = 8, TB_ROWS = TB_THREADS * TB_ITEMS;
+
+struct __attribute__((packed, aligned(4))) TileI4 { int32_t v[4]; };   // 16 bytes at int32 alignment (adopted columns may be views)
 
 // VERIFY (with FILL): `bsum` is the scanned block-sum array remembered from an earlier call on this batch and tile
 // size (the count pass, the scan and the host round trip are skipped); every block checks its own total against it and
@@ -108,82 +113,71 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
                                                            uint32_t *__restrict__ misc, int64_t cap) {
   // (cap = entries of `tiles`: the count may be one remembered from an earlier call -- a batch that was changed since
   //  must not write behind the table before the host notices)
-  __shared__ uint32_t s_tot[TB_ITEMS][TB_THREADS / 64];
+  __shared__ uint32_t s_tot[TB_THREADS / 64];
   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) {       // the report kernels' counters start at zero (saves three memsets)
     misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0;    // pool cursor, output rows, heavy tiles, largest heavy tile
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t base = (int64_t)blockIdx.x * TB_ROWS + threadIdx.x;     // item i is row base + i*TB_THREADS: coalesced
-  uint32_t c[TB_ITEMS];
-  RowTiles rt[TB_ITEMS];
+  const int64_t x0 = (int64_t)blockIdx.x * TB_ROWS + (int64_t)threadIdx.x * TB_ITEMS;
+  int32_t st[TB_ITEMS + 1], rn[TB_ITEMS + 1];              // [0] = the predecessor of the thread's first row
+#pragma unroll
+  for (int i = 0; i <= TB_ITEMS; i++) { st[i] = 0; rn[i] = 0; }
+  if (x0 < n) {
+    if (x0 > 0) { st[0] = start[x0 - 1]; rn[0] = rname[x0 - 1]; }
+    if (x0 + TB_ITEMS <= n) {
+#pragma unroll
+      for (int q = 0; q < TB_ITEMS / 4; q++) {
+        const TileI4 a = *reinterpret_cast<const TileI4 *>(start + x0 + 4 * q), c = *reinterpret_cast<const TileI4 *>(rname + x0 + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { st[1 + 4 * q + k] = a.v[k]; rn[1 + 4 * q + k] = c.v[k]; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TB_ITEMS; i++) if (x0 + i < n) { st[1 + i] = start[x0 + i]; rn[1 + i] = rname[x0 + i]; }
+    }
+  }
+  uint32_t c[TB_ITEMS], tot = 0;
 #pragma unroll
   for (int i = 0; i < TB_ITEMS; i++) {
-    const int64_t x = base + (int64_t)i * TB_THREADS;
     c[i] = 0;
-    rt[i].lo = 0; rt[i].b = -1; rt[i].hi_a = 0; rt[i].hi_b = -1; rt[i].bp = 0;
-    if (x < n) {
-      rt[i] = row_tiles(start, rname, x, lmax, sh);
-      if (rt[i].b >= rt[i].lo) c[i] = (uint32_t)(rt[i].b - rt[i].lo + 1);
+    if (x0 + i < n) {
+      const RowTiles rt = row_tiles(st[1 + i], rn[1 + i], st[i], rn[i], x0 + i > 0, lmax, sh);
+      if (rt.b >= rt.lo) c[i] = (uint32_t)(rt.b - rt.lo + 1);
     }
+    tot += c[i];
   }
-  if (!FILL) {
-    uint32_t t = 0;
+  const uint32_t inc = wave_scan_u32(tot);
+  if (lane == 63) s_tot[wave] = inc;
+  __syncthreads();
+  uint32_t btot = 0, wbase = 0;
 #pragma unroll
-    for (int i = 0; i < TB_ITEMS; i++) t += c[i];
-    t = wave_sum_u32(t);
-    if (lane == 0) s_tot[0][wave] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+  for (int w = 0; w < TB_THREADS / 64; w++) { const uint32_t t = s_tot[w]; if (w < wave) wbase += t; btot += t; }
+  if (!FILL) {
+    if (threadIdx.x == 0) bsum[blockIdx.x] = btot;
     return;
   }
-  // exclusive scan in row order (item-major, then thread): wave scans per item, one pass over the 32 wave totals
-  uint32_t inc[TB_ITEMS];
-#pragma unroll
-  for (int i = 0; i < TB_ITEMS; i++) inc[i] = c[i];
-  // (shuffles here: eight DPP scans measured slower in this kernel, 77 against 59 us on 10 M rows)
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-    for (int i = 0; i < TB_ITEMS; i++) {
-      const uint32_t t = __shfl_up(inc[i], d, 64);
-      if (lane >= d) inc[i] += t;
+  if constexpr (VERIFY) {
+    if (threadIdx.x == 0) {
+      const uint32_t expect = (blockIdx.x + 1 < gridDim.x ? bsum[blockIdx.x + 1] : (uint32_t)cap) - bsum[blockIdx.x];
+      if (btot != expect) atomicMax(misc, 0xFFFFFFFFu);
+      else if (blockIdx.x == 0) atomicMax(misc, (uint32_t)cap);
     }
   }
-  if (lane == 63) {
-#pragma unroll
-    for (int i = 0; i < TB_ITEMS; i++) s_tot[i][wave] = inc[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {                                  // exclusive scan of the 32 (item, wave) totals by one wavefront
-    constexpr int NT = TB_ITEMS * (TB_THREADS / 64);
-    static_assert(NT <= 64, "one wavefront scans the wave totals");
-    uint32_t *flat = &s_tot[0][0];
-    const uint32_t t = lane < NT ? flat[lane] : 0u;
-    const uint32_t inc2 = wave_scan_u32(t);
-    if (lane < NT) flat[lane] = bsum[blockIdx.x] + inc2 - t;   // + the tiles created before this block (already scanned)
-    if constexpr (VERIFY) {
-      if (lane == 63) {
-        const uint32_t expect = (blockIdx.x + 1 < gridDim.x ? bsum[blockIdx.x + 1] : (uint32_t)cap) - bsum[blockIdx.x];
-        if (inc2 != expect) atomicMax(misc, 0xFFFFFFFFu);
-        else if (blockIdx.x == 0) atomicMax(misc, (uint32_t)cap);
-      }
-    }
-  }
-  __syncthreads();
+  uint32_t before = bsum[blockIdx.x] + wbase + inc - tot;  // tiles created by rows before the thread's first row
   const int64_t T = 1LL << sh;
 #pragma unroll
   for (int i = 0; i < TB_ITEMS; i++) {
-    const int64_t x = base + (int64_t)i * TB_THREADS;
-    if (x >= n) continue;
-    const uint32_t before = inc[i] - c[i] + s_tot[i][wave];      // tiles created by rows < x
-    for (int64_t t = rt[i].hi_a; t <= rt[i].hi_b; t++) {          // tiles this row closes
-      const int64_t j = (int64_t)before - 1 - (rt[i].bp - t);
+    const int64_t x = x0 + i;
+    if (x >= n) break;
+    const RowTiles rt = row_tiles(st[1 + i], rn[1 + i], st[i], rn[i], x > 0, lmax, sh);
+    for (int64_t t = rt.hi_a; t <= rt.hi_b; t++) {          // tiles this row closes
+      const int64_t j = (int64_t)before - 1 - (rt.bp - t);
       if (j >= 0 && j < cap) tiles[j].row_hi = (int32_t)x;
     }
     if (c[i]) {
-      const int32_t r = rname[x];
-      for (uint32_t k = 0; k < c[i]; k++) {                       // tiles this row creates: it IS their row_lo
-        const int64_t t = rt[i].lo + k;                           // (the first row with start >= pos0 - lmax + 1)
+      const int32_t r = rn[1 + i];
+      for (uint32_t k = 0; k < c[i]; k++) {                 // tiles this row creates: it IS their row_lo
+        const int64_t t = rt.lo + k;                        // (the first row with start >= pos0 - lmax + 1)
         if ((int64_t)before + k >= cap) break;
         Tile *td = tiles + before + k;
         td->pos0 = t * T - kPosBias;
@@ -199,13 +193,14 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
         td->slot = slot;
       }
     }
-    if (x == n - 1) {                                             // the end of the table closes what the last row reaches
-      const int64_t sx = tile_of(start[x], sh);
-      for (int64_t t = sx; t <= rt[i].b; t++) {
-        const int64_t j = (int64_t)before + c[i] - 1 - (rt[i].b - t);
+    if (x == n - 1) {                                       // the end of the table closes what the last row reaches
+      const int64_t sx = tile_of(st[1 + i], sh);
+      for (int64_t t = sx; t <= rt.b; t++) {
+        const int64_t j = (int64_t)before + c[i] - 1 - (rt.b - t);
         if (j >= 0 && j < cap) tiles[j].row_hi = (int32_t)n;
       }
     }
+    before += c[i];
   }
 }
 
