@@ -1537,7 +1537,8 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   constexpr int T = MHLF_T;
   RowStats st;
   int32_t nt = 0;
-  EPI_TRY(build_tiles(b, s, T, &st, &nt));
+  bool nt_hinted = false;                                  // (a remembered tile count is verified at the synchronisation below)
+  EPI_TRY(build_tiles(b, s, T, &st, &nt, &nt_hinted));
   const int gc = pick_mhl_group(st.max_len);
   if (gc == 0 || getenv("EPIHIP_MHL_GROUP")) return EPI_OK;  // reads longer than one block of lanes: wavefront-per-read path
   b->last_ntiles = nt;
@@ -1613,7 +1614,13 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    EPI_TRY(read_scalars(b, s, cursor, 12, host));         // {overflow rows handed out, total rows, deep tiles}
+    uint32_t host4[4];
+    EPI_TRY(read_scalars(b, s, cursor - 1, 16, host4));    // {tile count, overflow rows handed out, total rows, deep tiles}
+    if (nt_hinted && host4[0] != (uint32_t)nt) {
+      for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
+      return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host4[0], nt);
+    }
+    host[0] = host4[1]; host[1] = host4[2]; host[2] = host4[3];
 #ifdef EPI_CHECK
     {
       uint32_t d[8];
