@@ -191,11 +191,13 @@ __device__ __forceinline__ bool epi_dev_check(uint32_t *dbg, bool ok, uint32_t c
 // rows 1 and 3 and row_bcast:31 into rows 2 and 3): VALU instructions, where __shfl_* is a ds_bpermute through the
 // LDS pipe with ~100 cycles of latency.  Device code only.
 #ifdef __HIPCC__
+// (bound_ctrl = true on the row shifts: a lane without a source reads 0, the same value as `old` = 0 would give it, and the
+//  compiler can then fold move and add into one v_add_u32_dpp instead of v_mov 0 + v_mov_dpp + v_add)
 __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {      // inclusive prefix sum over the 64 lanes
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
   return v;

@@ -274,7 +274,7 @@ __device__ __forceinline__ bool mhl_keep(uint32_t h, uint32_t oo_m, uint32_t oo_
 // __shfl_* is a ds_bpermute through the LDS pipe with ~100 cycles of latency, and pass 1 chains about 35 of them per
 // wavefront.  A lane whose partner lies outside its group gets another group's value (or 0): callers mask those lanes.
 template <int CTRL>
-__device__ __forceinline__ uint32_t lane_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t lane_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }   // (no source: 0)
 // (row shifts do not cross the rows of 16 lanes: groups of 32 or 64 lanes keep the shuffles)
 template <int G, int D>
 __device__ __forceinline__ uint32_t grp_up(uint32_t v) {             // value of lane - D
@@ -718,7 +718,7 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
 // row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): no LDS traffic, unlike __shfl_up (ds_bpermute)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ uint32_t mhl_dpp(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);   // lanes without a source get 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, ROWS == 0xF);   // lanes without a source get 0
 }
 template <int CTRL, int ROWS>
 __device__ __forceinline__ unsigned long long mhl_dpp(unsigned long long v) {
