@@ -54,7 +54,8 @@ def _worker(rank, world, port, name, outdir):
                                         t["strand"][lo:hi], t["start"][lo:hi])
     eng = D.HipShardEngine(shard)
     for thr, rctx in ((True, "CG"), (False, "CX")):
-        rep = D.sharded_cytosine_report(eng, threshold_reads=thr, report_context=rctx, gather=True)
+        for _ in range(2):                                  # (the second call runs on the remembered, verified tile index)
+            rep = D.sharded_cytosine_report(eng, threshold_reads=thr, report_context=rctx, gather=True)
         if rank == 0:
             np.savez(os.path.join(outdir, "%s_%s.npz" % (name, rctx)), **{k: v.cpu().numpy() for k, v in rep.items()})
     for hmax in (0, 2):
