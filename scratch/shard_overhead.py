@@ -20,8 +20,10 @@ first, last = eng.key_range()
 keys = np.array([first, first + 1], dtype=np.int64); owned = np.ones(2, dtype=np.int32)
 from epialleler_amd.api import CONTEXT_TO_BASES as C
 c = C["CG"]
+thr = (c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
 def shared_step():
-    p = eng.threshold(c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
-    eng.cx_accumulate(p, c["ctx_meth"], keys, owned)
+    eng.cx_accumulate_fused(thr, c["ctx_meth"], keys, owned)
     return eng.cx_finish(c["ctx_meth"])
-print("sharded with 2 shared tiles (no collective) %.3f ms" % t(shared_step))
+print("sharded with 2 shared tiles, fused (no collective) %.3f ms" % t(shared_step))
+keys = np.arange(first, first + 14, dtype=np.int64); owned = np.ones(14, dtype=np.int32)
+print("sharded with 14 shared tiles, fused (no collective) %.3f ms" % t(shared_step))
