@@ -19,7 +19,14 @@
 //    land in ONE LDS cell.
 //  * Counters are u8, four positions per dword, (n | M) of a context side by side in one u64: ONE ds_add_u64 per
 //    dword of xm and reported context (issued only by lanes whose dword holds a call) instead of one LDS atomic per
-//    base.  u8 counters are folded into u16 pairs every 255 rows (a row adds at most 1 per position and counter).
+//    base.  LEAN kernel (batches in which no position is covered by more than 255 rows, RowStats::deep == 0 -- any WGS
+//    data): the u8 counters cannot overflow, the emit reads them directly; 24 KiB of LDS, 256-thread workgroups, six
+//    per CU.  General kernel (pile-ups): the u8 counters are folded into u16 pairs every 255 rows (a row adds at most
+//    1 per position and counter); 40 KiB, 512-thread workgroups.
+//  * Lane shape: G lanes x NU chunks of 16 bytes per row, the smallest G * NU that holds the longest row
+//    (pick_cx_shape; PE150: 4 x 5, 16 rows per wavefront step).  The kernel is bound by integer VALU issue (plain
+//    2-operand ops 2 cycles per wavefront on gfx950, perm / compare / 3-operand / DPP / 64-bit ops 4), so idle chunk
+//    slots and per-step set-up are what the shape minimises.
 //  * Coverage is a difference array (+1 at the first, -1 behind the last position of a row: two LDS atomics per row,
 //    both strands packed into one dword); skipped / doubled codes go to a second u8 array that is folded into it.
 //  * Fused thresholding (FUSED = true; the default generateCytosineReport call: report.context == threshold.context,
