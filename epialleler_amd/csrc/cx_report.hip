@@ -1028,19 +1028,22 @@ static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : CXP_T; }
 // Lanes per row and 16-byte chunks per lane.  Whole rows (fused thresholding) must fit one visit of G * NU chunks
 // wherever they start inside their first chunk; so must the slice of a row inside a tile (at most T / 16 + 1 chunks).
 // The smallest G * NU that holds them wins: idle chunk slots cost the same VALU as used ones, and fewer lanes per row
-// are more rows per wavefront step (PE150: 20 chunks = 4 lanes x 5, against 8 x 3 = 24 slots).  Five chunks per lane
-// need ~80 VGPRs, which only the lean kernel's 256-thread workgroups have.  Returned as G * 8 + NU.
+// are more rows per wavefront step (PE150: 20 chunks = 4 lanes x 5, against 8 x 3 = 24 slots).  Four to six chunks per
+// lane need ~80 VGPRs, which only the lean kernel's 256-thread workgroups have.  Returned as G * 8 + NU.
 static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
   const int64_t span = (fused ? (int64_t)max_len : (max_len < T ? max_len : T)) + (CX_CH - 1);
   const int chunks = (int)((span + CX_CH - 1) / CX_CH);
 #ifdef EPI_CX_FORCE_SHAPE                                  // timing builds only: (G, NU) = (EPI_CX_FORCE_SHAPE / 8, % 8)
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
-  for (int g = fused ? 4 : 8; g <= 64; g <<= 1) {
-    if (g * 3 >= chunks) return g * 8 + 3;
-    if (lean && g * 5 >= chunks) return g * 8 + 5;
-  }
-  return 64 * 8 + 3;
+  int best = 0, best_cap = 0;
+  for (int g = fused ? 4 : 8; g <= 64; g <<= 1)
+    for (int nu = 3; nu <= (lean ? 6 : 3); nu++) {
+      const int cap = g * nu;
+      if (cap < chunks) continue;
+      if (!best || cap < best_cap) { best = g * 8 + nu; best_cap = cap; }   // ties: the earlier (fewer lanes per row) wins
+    }
+  return best ? best : 64 * 8 + 3;
 }
 static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3; }
 
@@ -1106,8 +1109,12 @@ static void launch_cxp(bool heavy, int np, int g, int nt, dim3 grid, hipStream_t
 static void launch_cx(bool heavy, int np, bool fused, bool lean, int shape, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   const int g = shape >> 3;
   if (np > 1) { launch_cxp(heavy, np, g, nt, grid, s, a); return; }   // several contexts: one packed-pair atomic per base
-  if (!heavy && lean && (shape & 7) == 5) {                // one context, 2048-position tiles, five chunks per lane
-    if (fused) launch_cx_tiles<CX_T1, 5, 1, true, true>(g, nt, s, a); else launch_cx_tiles<CX_T1, 5, 1, false, true>(g, nt, s, a);
+  if (!heavy && lean && (shape & 7) > 3) {                 // one context, 2048-position tiles, four to six chunks per lane
+    switch (shape & 7) {
+      case 4: if (fused) launch_cx_tiles<CX_T1, 4, 1, true, true>(g, nt, s, a); else launch_cx_tiles<CX_T1, 4, 1, false, true>(g, nt, s, a); break;
+      case 5: if (fused) launch_cx_tiles<CX_T1, 5, 1, true, true>(g, nt, s, a); else launch_cx_tiles<CX_T1, 5, 1, false, true>(g, nt, s, a); break;
+      default: if (fused) launch_cx_tiles<CX_T1, 6, 1, true, true>(g, nt, s, a); else launch_cx_tiles<CX_T1, 6, 1, false, true>(g, nt, s, a); break;
+    }
     return;
   }
   if (fused) launch_cx_g<CX_T1, 3, 1, true>(heavy, lean, g, nt, grid, s, a);
