@@ -37,6 +37,8 @@ WORKLOADS = {
     "cfg2u": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", uniform=True,
                   desc="as cfg2 with uniform-random starts (sorted on device), template lengths 240-360 and a 50-byte "
                        "0xFB gap in every fourth template"),
+    "cfg2n": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CG",
+                  desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE): SURVEY 8d's un-thresholded config 2"),
     "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX",
                    desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE, report.context='CX')"),
     "cfg3": dict(rows=100_000_000, strong=True, read_len=300, kind="cx", threshold=True, report_context="CG",

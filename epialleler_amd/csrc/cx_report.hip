@@ -1037,7 +1037,7 @@ static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
   int best = 0, best_cap = 0;
-  for (int g = fused ? 4 : 8; g <= 64; g <<= 1)
+  for (int g = (fused || lean) ? 4 : 8; g <= 64; g <<= 1)
     for (int nu = 3; nu <= (lean ? 6 : 3); nu++) {
       const int cap = g * nu;
       if (cap < chunks) continue;
@@ -1051,7 +1051,7 @@ template <int T, int NU, int NP, bool FUSED, bool LEAN>
 static void launch_cx_tiles(int g, int nt, hipStream_t s, const Cx2Args &a) {
   const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
-    case 4: if constexpr (FUSED) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); } break;
+    case 4: if constexpr (FUSED || LEAN) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); } break;
     case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
     case 16: hipLaunchKernelGGL((k_cx_tiles<T, 16, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
     case 32: hipLaunchKernelGGL((k_cx_tiles<T, 32, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
