@@ -26,6 +26,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <deque>
 #include <new>
 #include <atomic>
 #include <numeric>
@@ -416,7 +417,25 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   // of BGZF blocks, index the complete records, pack the complete templates, carry the rest (a record cut by the
   // window, or the records of a template whose mate is still to come) over to the next window.
   const size_t window = opt.window_kib > 0 ? (size_t)opt.window_kib * 1024 : (size_t)256 << 20;
-  std::vector<uint8_t> buf;
+  // the window of inflated bytes: grown without clearing it (std::vector::resize would zero-fill hundreds of megabytes on
+  // one thread before every inflate)
+  struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    size_t size() const { return n; }
+    uint8_t &operator[](size_t i) { return p[i]; }
+    void resize(size_t m) {
+      if (m > cap) {
+        uint8_t *q = static_cast<uint8_t *>(realloc(p, m));
+        if (!q) throw std::bad_alloc();
+        p = q; cap = m;
+      }
+      n = m;
+    }
+    void release() { free(p); p = nullptr; n = cap = 0; }
+  } buf;
   size_t carry = 0, bi = 0, hdr_end = 0;
   bool header_done = false, checked = false, paired = false, tMM = false;
   std::vector<std::string> names;
@@ -603,6 +622,9 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     return EPI_OK;
   };
 
+  std::deque<Packed> segs;                                  // what the packing threads produced, kept until the ordered copy
+  std::vector<const uint8_t *> src;                         // per template: its bytes inside a segment ...
+  std::vector<int32_t> len;                                 // ... and how many
   // packs records [0, r_end) of the current window with K threads and appends the templates to P
   auto pack_window = [&](size_t r_end) -> int {
     size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
@@ -634,14 +656,18 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     for (auto &t : th) t.join();
     for (size_t k = 0; k < K; k++)
       if (rcs[k] != EPI_OK) return fail(rcs[k], "%s", msgs[k].c_str());
+    // the packed bytes stay where the threads wrote them (a segment per thread and window): only the small columns are
+    // concatenated, and the final ordered copy reads the segments directly
     for (size_t k = 0; k < K; k++) {
-      const Packed &q = part[k];
-      const int64_t shift = (int64_t)P.bytes.size();
+      segs.push_back(std::move(part[k]));
+      const Packed &q = segs.back();
       P.rname.insert(P.rname.end(), q.rname.begin(), q.rname.end());
       P.strand.insert(P.strand.end(), q.strand.begin(), q.strand.end());
       P.start.insert(P.start.end(), q.start.begin(), q.start.end());
-      for (size_t i = 1; i < q.off.size(); i++) P.off.push_back(q.off[i] + shift);
-      P.bytes.insert(P.bytes.end(), q.bytes.begin(), q.bytes.end());
+      for (size_t i = 0; i + 1 < q.off.size(); i++) {
+        src.push_back(q.bytes.data() + q.off[i]);
+        len.push_back((int32_t)(q.off[i + 1] - q.off[i]));
+      }
     }
     return EPI_OK;
   };
@@ -741,9 +767,9 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     if (final) break;
   }
   if (!tMM && paired && P.rname.empty()) {                  // the reference pushes its (never opened) template all the same, :155
-    P.rname.push_back(1); P.strand.push_back(0); P.start.push_back(trim5 + 1); P.off.push_back(0);
+    P.rname.push_back(1); P.strand.push_back(0); P.start.push_back(trim5 + 1); src.push_back(nullptr); len.push_back(0);
   }
-  { std::vector<uint8_t>().swap(buf); }
+  buf.release();
 
   lap("pack");
   // ---- templid := 0..N-1 ; setorder(rname, start) -- stable (R/internal.R:193-195) ----
@@ -754,7 +780,9 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     if (P.rname[a] != P.rname[b]) return P.rname[a] < P.rname[b];
     return P.start[a] < P.start[b];
   });
-  const size_t nbytes = P.bytes.size(), cap = (nbytes + 15) / 16 * 16 + 64;
+  size_t nbytes = 0;
+  for (size_t i = 0; i < n; i++) nbytes += (size_t)len[i];
+  const size_t cap = (nbytes + 15) / 16 * 16 + 64;
   void *xmp = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&xmp, cap, hipHostMallocDefault) == hipSuccess) out->pinned = 1;
@@ -770,15 +798,23 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     return fail(EPI_ERR_NOMEM, "epi_preprocess_bam: out of host memory");
   }
   int64_t w = 0;
-  for (size_t i = 0; i < n; i++) {
-    const uint32_t t = order[i];
-    const int64_t len = P.off[t + 1] - P.off[t];
-    out->off[i] = w;
-    if (len) memcpy(out->xm + w, P.bytes.data() + P.off[t], (size_t)len);
-    w += len;
-    out->rname[i] = P.rname[t]; out->strand[i] = P.strand[t]; out->start[i] = P.start[t];
-  }
+  for (size_t i = 0; i < n; i++) { out->off[i] = w; w += len[order[i]]; }
   out->off[n] = w;
+  {                                                        // the ordered copy, by ranges of output rows
+    size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
+    if (n < 4096) K = 1;
+    auto run = [&](size_t k) {
+      for (size_t i = n * k / K; i < n * (k + 1) / K; i++) {
+        const uint32_t t = order[i];
+        if (len[t]) memcpy(out->xm + out->off[i], src[t], (size_t)len[t]);
+        out->rname[i] = P.rname[t]; out->strand[i] = P.strand[t]; out->start[i] = P.start[t];
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < K; k++) th.emplace_back(run, k);
+    run(0);
+    for (auto &t : th) t.join();
+  }
   memset(out->xm + w, 0xFB, cap - (size_t)w);
   lap("sort+copy");
   out->n = (int64_t)n;
