@@ -776,10 +776,31 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   const size_t n = P.rname.size();
   std::vector<uint32_t> order(n);
   std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    if (P.rname[a] != P.rname[b]) return P.rname[a] < P.rname[b];
-    return P.start[a] < P.start[b];
-  });
+  {
+    auto less = [&](uint32_t a, uint32_t b) {
+      if (P.rname[a] != P.rname[b]) return P.rname[a] < P.rname[b];
+      return P.start[a] < P.start[b];
+    };
+    // stable: ranges sorted by the threads, then merged pairwise (std::inplace_merge keeps equal keys in order)
+    size_t K = 1;
+    while (K * 2 <= (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) && n / (K * 2) >= 65536) K *= 2;
+    std::vector<size_t> cut(K + 1);
+    for (size_t k = 0; k <= K; k++) cut[k] = n * k / K;
+    {
+      std::vector<std::thread> th;
+      for (size_t k = 1; k < K; k++) th.emplace_back([&, k]() { std::stable_sort(order.begin() + cut[k], order.begin() + cut[k + 1], less); });
+      std::stable_sort(order.begin() + cut[0], order.begin() + cut[1], less);
+      for (auto &t : th) t.join();
+    }
+    for (size_t w = 1; w < K; w *= 2) {                      // merge runs of w ranges
+      std::vector<std::thread> th;
+      for (size_t k = 0; k + w < K; k += 2 * w) {
+        const size_t lo = cut[k], mid = cut[k + w], hi = cut[k + 2 * w < K ? k + 2 * w : K];
+        th.emplace_back([&, lo, mid, hi]() { std::inplace_merge(order.begin() + lo, order.begin() + mid, order.begin() + hi, less); });
+      }
+      for (auto &t : th) t.join();
+    }
+  }
   size_t nbytes = 0;
   for (size_t i = 0; i < n; i++) nbytes += (size_t)len[i];
   const size_t cap = (nbytes + 15) / 16 * 16 + 64;

@@ -177,3 +177,25 @@ def test_malformed_pairs_and_truncation(ea, tmp_path):
     with pytest.raises(ValueError) as ei:
         ea.preprocessBam(_raw_bam(tmp_path / "long.bam", [_rec(), (len(_rec()) + 100, _rec())]))
     assert "truncated BAM record" in str(ei.value)
+
+
+def test_threads_give_the_same_table_on_a_generated_bam(tmp_path):
+    """150 k templates (enough for the threaded range sort + pairwise merges and several packing segments): one thread
+    and eight threads, whole file and 4 MiB windows, must produce the same sorted table byte for byte."""
+    import epialleler_amd as ea
+    from epialleler_amd import synth
+    path = str(tmp_path / "gen.bam")
+    synth.write_bam_paired(path, 150000)
+    ref = None
+    for nt, win in ((1, 0), (8, 0), (8, 4096)):
+        bam = ea.preprocessBam(path, nthreads=nt, window_kib=win)
+        h = bam.host
+        key = (h["rname"].astype(np.int64) << 32) | h["start"]
+        assert np.all(np.diff(key) >= 0)
+        cur = {k: np.array(h[k]) for k in ("xm", "off", "rname", "strand", "start")}
+        if ref is None:
+            ref = cur
+            assert bam.n == 150000 and int(cur["off"][-1]) == 150000 * 300
+        else:
+            for k in ref:
+                assert np.array_equal(ref[k], cur[k]), (k, nt, win)
