@@ -642,6 +642,13 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     auto run = [&](size_t k) {
       try {
         part[k].off.push_back(0);
+        {                                                   // (one allocation instead of a doubling series per column)
+          size_t bases = 0;
+          for (size_t i = cut[k]; i < cut[k + 1]; i++) bases += (size_t)recs[i].l_seq;
+          const size_t nrec = cut[k + 1] - cut[k];
+          part[k].bytes.reserve(bases + bases / 8 + 4096);
+          part[k].off.reserve(nrec + 2); part[k].rname.reserve(nrec + 1); part[k].strand.reserve(nrec + 1); part[k].start.reserve(nrec + 1);
+        }
         rcs[k] = tMM ? pack_mm(cut[k], cut[k + 1], part[k]) : paired ? pack_pe(cut[k], cut[k + 1], part[k]) : pack_se(cut[k], cut[k + 1], part[k]);
         if (rcs[k] != EPI_OK) msgs[k] = epi_last_error();   // the message is thread-local
       } catch (const std::bad_alloc &) {
