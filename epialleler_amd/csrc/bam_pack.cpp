@@ -447,8 +447,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   if (opt.skip_duplicates) skip_flags |= 1024;
   if (opt.skip_supplementary) skip_flags |= 2048;
   const int trim5 = opt.trim5, trim3 = opt.trim3;
-  Packed P;
-  P.off.push_back(0);
+  Packed P;                                                 // the small columns of all templates (the bytes stay in `segs`)
 
   // ---- .readBam: skip flags (R/internal.R:173-177, above) and the packers ----
   // a record that enters a template must be self-consistent: the CIGAR consumes exactly the stored bases, XM covers
