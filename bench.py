@@ -413,7 +413,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
-                       "inputs": "resident in HBM", "sharding": ("row ranges; shared tiles all-reduced (RCCL); output rows %s"
+                       "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (RCCL); output rows %s"
                                     % ("gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,

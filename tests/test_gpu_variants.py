@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_CX_SLOT": "3", "EPIHIP_HEAVY_ROWS": "500"},                 # nearly every tile outgrows its pool slot
     {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
+    {"EPIHIP_TILE_HINT": "0"},                                           # tile index counted and scanned by every call (no remembered offsets)
     {"EPIHIP_CX_LEAN": "0"},                                             # single-context CX reports: the general kernel (u16 copy of the
                                                                          # u8 counters, folds) also where no position is deeper than 255 rows
     {"EPIHIP_CX_LEAN": "0", "EPIHIP_HEAVY_ROWS": "100", "EPIHIP_CX_SLOT": "3"},
