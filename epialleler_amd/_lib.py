@@ -98,6 +98,9 @@ _SIGS = {
     "epi_batch_cx_report": (C.c_int, [_VP, _VP, _CS, C.POINTER(CxTable)]),
     "epi_batch_cytosine_report": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _CS, _VP, C.POINTER(CxTable)]),
     "epi_batch_mhl_report": (C.c_int, [_VP, _CS, C.c_int, C.c_int, _F64, C.POINTER(MhlTable)]),
+    "epi_batch_cx_report_begin": (C.c_int, [_VP, _VP, _CS, C.POINTER(_I64)]),
+    "epi_batch_cytosine_report_begin": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _CS, _VP, C.POINTER(_I64)]),
+    "epi_batch_mhl_report_begin": (C.c_int, [_VP, _CS, C.c_int, C.c_int, _F64, C.POINTER(_I64)]),
     "epi_default_engine": (C.c_int, [C.POINTER(_VP)]),
     "epi_batch_nrows": (_I64, [_VP]),
     "epi_batch_threshold_reads_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _VP]),
@@ -128,6 +131,7 @@ _SIGS = {
     "epi_prof_enable": (None, [C.c_int]),
     "epi_prof_get": (C.c_int, [_CS, C.POINTER(_F64), C.POINTER(_I64)]),
     "epi_prof_reset": (None, []),
+    "epi_options_reload": (None, []),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
@@ -142,13 +146,19 @@ def load():
         raise EpihipError(EPI_ERR_NODEVICE,
                           "libepihip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                           "there is no CPU fallback" % LIB_PATH)
-    try:
-        import torch  # noqa: F401  (loads torch's libamdhip64 first; ours resolves to the same SONAME)
-    except Exception:
-        pass
+    host_only = bool(os.environ.get("EPIHIP_HOST_ONLY"))     # `make asan` library: BAM producer + report writer only
+    if not host_only:
+        try:
+            import torch  # noqa: F401  (loads torch's libamdhip64 first; ours resolves to the same SONAME)
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if host_only:
+                continue
+            raise EpihipError(EPI_ERR_STATE, "%s does not export %s" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -197,7 +197,15 @@ def preprocessBam(bam_file, paired=None, min_mapq=0, min_baseq=0, min_prob=-1, h
     # they are released when the ProcessedBam goes away
     keep = _TemplatesOwner(t)
     n = t.n
-    view = lambda ptr, k: np.ctypeslib.as_array(ptr, shape=(max(k, 1),))[:k]
+
+    def view(ptr, k):
+        # every array owns its buffer: .base is a ctypes array that carries the _TemplatesOwner, so
+        # `preprocessBam(p).host["xm"]` stays valid after the ProcessedBam itself is gone
+        if k <= 0 or not ptr:
+            return np.empty(0, dtype=np.dtype(ptr._type_))
+        carr = (ptr._type_ * int(k)).from_address(C.addressof(ptr.contents))
+        carr._owner = keep
+        return np.frombuffer(carr, dtype=np.dtype(ptr._type_))
     levels = tuple(t.target_names[i].decode("latin1") for i in range(t.n_targets))
     bam = ProcessedBam.from_arrays(view(t.xm, t.nbytes), view(t.off, n + 1), view(t.rname, n), view(t.strand, n),
                                    view(t.start, n), levels, keepalive=keep)

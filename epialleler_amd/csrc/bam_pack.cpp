@@ -341,7 +341,11 @@ extern "C" {
 
 void epi_templates_free(epi_templates *t) {
   if (!t) return;
+#ifdef EPI_HOST_ONLY
+  free(t->xm);                                             // (sanitizer build: no HIP runtime, the bytes came from malloc)
+#else
   if (t->xm) { if (t->pinned) (void)hipHostFree(t->xm); else free(t->xm); }
+#endif
   free(t->off); free(t->rname); free(t->strand); free(t->start);
   if (t->target_names) { for (int32_t i = 0; i < t->n_targets; i++) free(t->target_names[i]); free(t->target_names); }
   memset(t, 0, sizeof(*t));
@@ -404,7 +408,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   else { memset(&opt, 0, sizeof(opt)); opt.skip_secondary = opt.skip_qcfail = opt.skip_supplementary = 1; opt.paired = -1; opt.nthreads = 1; opt.min_prob = -1; opt.highest_prob = 1; }
   if (opt.trim5 < 0 || opt.trim3 < 0) return fail(EPI_ERR_ARG, "trim must be non-negative");
 
-  const bool timing = getenv("EPIHIP_BAM_TIMING") != nullptr;
+  const bool timing = epi::options().bam_timing != 0;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tm0 = tnow();
   auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[bam] %-10s %.3f s\n", what, t - tm0); tm0 = t; } };
@@ -811,9 +815,13 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   for (size_t i = 0; i < n; i++) nbytes += (size_t)len[i];
   const size_t cap = (nbytes + 15) / 16 * 16 + 64;
   void *xmp = nullptr;
+#ifdef EPI_HOST_ONLY
+  xmp = malloc(cap); out->pinned = 0;                      // host-only sanitizer build (`make asan`)
+#else
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&xmp, cap, hipHostMallocDefault) == hipSuccess) out->pinned = 1;
   else { (void)hipGetLastError(); xmp = malloc(cap); out->pinned = 0; }
+#endif
   out->xm = (uint8_t *)xmp;
   out->off = (int64_t *)malloc((n + 1) * sizeof(int64_t));
   out->rname = (int32_t *)malloc((n + 1) * sizeof(int32_t));

@@ -14,9 +14,7 @@ static epi_engine *g_default_engine = nullptr;
 static int default_engine(epi_engine **out) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_default_engine) {
-    int dev = 0;
-    if (const char *e = getenv("EPIHIP_DEVICE")) dev = atoi(e);
-    EPI_TRY(epi_engine_create(dev, &g_default_engine));
+    EPI_TRY(epi_engine_create(options().device, &g_default_engine));
   }
   *out = g_default_engine;
   return EPI_OK;
@@ -51,9 +49,7 @@ int epi_batch_threshold_reads(epi_batch *b, const char *ctx_meth, const char *ct
   int32_t *d = b->host_io.as<int32_t>();
   EPI_TRY(epi_batch_threshold_reads_dev(b, ctx_meth, ctx_unmeth, ooctx_meth ? ooctx_meth : "", ooctx_unmeth ? ooctx_unmeth : "",
                                         min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac, d, s));
-  EPI_HIP(hipMemcpyAsync(pass_out, d, (size_t)b->n * 4, hipMemcpyDeviceToHost, s));
-  EPI_HIP(hipStreamSynchronize(s));
-  return EPI_OK;
+  return copy_to_host(b->eng, pass_out, d, (size_t)b->n * 4, s);
 }
 
 int epi_batch_get_xm_beta(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, double *beta_out) {
@@ -64,9 +60,7 @@ int epi_batch_get_xm_beta(epi_batch *b, const char *ctx_meth, const char *ctx_un
   EPI_TRY(b->host_io.ensure((size_t)b->n * 8));
   double *d = b->host_io.as<double>();
   EPI_TRY(epi_batch_get_xm_beta_dev(b, ctx_meth, ctx_unmeth, d, s));
-  EPI_HIP(hipMemcpyAsync(beta_out, d, (size_t)b->n * 8, hipMemcpyDeviceToHost, s));
-  EPI_HIP(hipStreamSynchronize(s));
-  return EPI_OK;
+  return copy_to_host(b->eng, beta_out, d, (size_t)b->n * 8, s);
 }
 
 static int cx_table_to_host(epi_batch *b, int64_t nrow, hipStream_t s, epi_cx_table *out) {
@@ -83,10 +77,9 @@ static int cx_table_to_host(epi_batch *b, int64_t nrow, hipStream_t s, epi_cx_ta
   return EPI_OK;
 }
 
-int epi_batch_cx_report(epi_batch *b, const int32_t *pass, const char *ctx, epi_cx_table *out) {
-  if (!out) return fail(EPI_ERR_ARG, "epi_batch_cx_report: out is NULL");
-  memset(out, 0, sizeof(*out));
-  if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_cx_report: bad arguments");
+int epi_batch_cx_report_begin(epi_batch *b, const int32_t *pass, const char *ctx, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cx_report_begin: bad arguments");
+  *nrow_out = 0;
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = b->eng->stream;
   const int32_t *d_pass = nullptr;
@@ -95,9 +88,31 @@ int epi_batch_cx_report(epi_batch *b, const int32_t *pass, const char *ctx, epi_
     EPI_HIP(hipMemcpyAsync(b->host_io.p, pass, (size_t)b->n * 4, hipMemcpyHostToDevice, s));
     d_pass = b->host_io.as<int32_t>();
   }
+  return epi_batch_cx_report_dev(b, d_pass, ctx, s, nrow_out);
+}
+
+int epi_batch_cx_report(epi_batch *b, const int32_t *pass, const char *ctx, epi_cx_table *out) {
+  if (!out) return fail(EPI_ERR_ARG, "epi_batch_cx_report: out is NULL");
+  memset(out, 0, sizeof(*out));
+  if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_cx_report: bad arguments");
   int64_t nrow = 0;
-  EPI_TRY(epi_batch_cx_report_dev(b, d_pass, ctx, s, &nrow));
-  return cx_table_to_host(b, nrow, s, out);
+  EPI_TRY(epi_batch_cx_report_begin(b, pass, ctx, &nrow));
+  return cx_table_to_host(b, nrow, b->eng->stream, out);
+}
+
+int epi_batch_cytosine_report_begin(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                                    const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                                    double max_ooctx_meth_frac, const char *ctx, int32_t *pass_out, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report_begin: bad arguments");
+  *nrow_out = 0;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  hipStream_t s = b->eng->stream;
+  int32_t *d_pass = nullptr;
+  if (pass_out && b->n > 0) { EPI_TRY(b->host_io.ensure((size_t)b->n * 8)); d_pass = b->host_io.as<int32_t>(); }
+  EPI_TRY(epi_batch_cytosine_report_dev(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
+                                        max_ooctx_meth_frac, ctx, d_pass, s, nrow_out));
+  if (d_pass) EPI_TRY(copy_to_host(b->eng, pass_out, d_pass, (size_t)b->n * 4, s));
+  return EPI_OK;
 }
 
 int epi_batch_cytosine_report(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
@@ -106,28 +121,25 @@ int epi_batch_cytosine_report(epi_batch *b, const char *ctx_meth, const char *ct
   if (!out) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report: out is NULL");
   memset(out, 0, sizeof(*out));
   if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_cytosine_report: bad arguments");
-  EPI_HIP(hipSetDevice(b->eng->device));
-  hipStream_t s = b->eng->stream;
-  int32_t *d_pass = nullptr;
-  if (pass_out && b->n > 0) { EPI_TRY(b->host_io.ensure((size_t)b->n * 8)); d_pass = b->host_io.as<int32_t>(); }
   int64_t nrow = 0;
-  EPI_TRY(epi_batch_cytosine_report_dev(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
-                                        max_ooctx_meth_frac, ctx, d_pass, s, &nrow));
-  if (d_pass) {
-    EPI_HIP(hipMemcpyAsync(pass_out, d_pass, (size_t)b->n * 4, hipMemcpyDeviceToHost, s));
-    EPI_HIP(hipStreamSynchronize(s));
-  }
-  return cx_table_to_host(b, nrow, s, out);
+  EPI_TRY(epi_batch_cytosine_report_begin(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac,
+                                          max_ooctx_meth_frac, ctx, pass_out, &nrow));
+  return cx_table_to_host(b, nrow, b->eng->stream, out);
+}
+
+int epi_batch_mhl_report_begin(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, int64_t *nrow_out) {
+  if (!b || !ctx || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_mhl_report_begin: bad arguments");
+  EPI_HIP(hipSetDevice(b->eng->device));
+  return epi_batch_mhl_report_dev(b, ctx, hmax, hmin, max_ooctx_meth_frac, b->eng->stream, nrow_out);
 }
 
 int epi_batch_mhl_report(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, epi_mhl_table *out) {
   if (!out) return fail(EPI_ERR_ARG, "epi_batch_mhl_report: out is NULL");
   memset(out, 0, sizeof(*out));
   if (!b || !ctx) return fail(EPI_ERR_ARG, "epi_batch_mhl_report: bad arguments");
-  EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = b->eng->stream;
   int64_t nrow = 0;
-  EPI_TRY(epi_batch_mhl_report_dev(b, ctx, hmax, hmin, max_ooctx_meth_frac, s, &nrow));
+  EPI_TRY(epi_batch_mhl_report_begin(b, ctx, hmax, hmin, max_ooctx_meth_frac, &nrow));
   const size_t m = (size_t)(nrow > 0 ? nrow : 1);
   int32_t *ic[5];
   double *dc[2];

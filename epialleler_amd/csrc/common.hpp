@@ -148,6 +148,12 @@ struct epi_batch {
 namespace epi {
 
 hipStream_t pick_stream(epi_batch *b, void *stream);
+// device -> host memory of the caller, complete on return.  Page-locked destinations are written by the DMA engine
+// directly; pageable ones (malloc, R vectors) go through the engine's two pinned staging buffers in chunks, the copy
+// out of buffer k overlapping the DMA into buffer k + 1.  `parts` may list several (dst, src, bytes) pieces: one pipeline.
+struct CopyPart { void *dst; const void *src; size_t bytes; };
+int copy_parts_to_host(epi_engine *eng, const CopyPart *parts, int nparts, hipStream_t s);
+int copy_to_host(epi_engine *eng, void *h_dst, const void *d_src, size_t bytes, hipStream_t s);
 int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst);  // sync D2H of a few bytes
 
 // util kernels (util.hip)
@@ -164,6 +170,28 @@ int fetch_row_stats(epi_batch *b, hipStream_t s);
 // `hinted` (may be null): the caller accepts a tile count remembered from an earlier call on this batch and tile size
 // (no host round trip in the middle of the index build) and verifies it against misc[0] at its own synchronisation.
 int build_tiles(epi_batch *b, hipStream_t s, int32_t tile_positions, RowStats *h_stats, int32_t *ntiles_out, bool *hinted = nullptr);
+
+// Result-neutral switches (test hooks that steer a call onto a rarely taken path, A/B shapes): read from the environment
+// ONCE per process into this struct; epi_options_reload() re-reads it (tests that change a hook inside one process).
+struct Options {
+  int device = 0;            // EPIHIP_DEVICE        device of the default engine (host-pointer entry points)
+  int cx_slot = -1;          // EPIHIP_CX_SLOT       pool rows per tile slot of the CX report (-1: adaptive)
+  int cx_lean = 1;           // EPIHIP_CX_LEAN=0     the general (u16-folding) CX kernel for every tile
+  int heavy_rows = 0;        // EPIHIP_HEAVY_ROWS    candidate rows above which a tile is split / set aside (0: default)
+  int tile_hint = 1;         // EPIHIP_TILE_HINT=0   tile index counted and scanned by every call
+  int mhl_fused = 1;         // EPIHIP_MHL_FUSED=0   two-kernel lMHL path for every batch
+  int mhl_slot = -1;         // EPIHIP_MHL_SLOT
+  int mhl_wg = 0;            // EPIHIP_MHL_WG        256 / 512 (two-kernel path)
+  int mhl_tile_group = 0;    // EPIHIP_MHL_TILE_GROUP
+  int mhl_multi = 0;         // EPIHIP_MHL_MULTI     wavefront-per-read pass 1
+  int mhl_group_g = 0, mhl_group_c = 0;   // EPIHIP_MHL_GROUP="G,C"
+  int mhl_sums = 0;          // EPIHIP_MHL_SUMS      32 / 64
+  int pr_group = 0;          // EPIHIP_GROUP         lanes per read of the general per-read kernel
+  int pr_rpg = 0;            // EPIHIP_PR_RPG
+  int pr_wide = 1;           // EPIHIP_PR_WIDE=0
+  int bam_timing = 0;        // EPIHIP_BAM_TIMING    phase times of the BAM reader on stderr
+};
+const Options &options();
 
 // profiling
 void prof_begin(const char *name, hipStream_t s);

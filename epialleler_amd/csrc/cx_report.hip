@@ -1273,7 +1273,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   uint32_t &slot_state = (ctx_mask & ~(1u << 7)) ? b->cx_slot_wide : b->cx_slot_cg;
   if (!slot_state) slot_state = (ctx_mask & ~(1u << 7)) ? (uint32_t)(3 * T) / 4 : (uint32_t)T / 8;
   uint32_t slot = slot_state > (uint32_t)(2 * T) ? (uint32_t)(2 * T) : slot_state;
-  if (const char *env = getenv("EPIHIP_CX_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }   // test hook
+  if (options().cx_slot >= 0 && options().cx_slot <= 2 * T) slot = (uint32_t)options().cx_slot;   // test hook (EPIHIP_CX_SLOT)
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
   size_t ovf_base = (size_t)nt * slot;
   for (;;) {
@@ -1289,7 +1289,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
   // u8 counters without folds when no position is covered by more than 255 rows (k_row_stats)
   bool lean = np == 1 && st.deep == 0;
-  if (const char *env = getenv("EPIHIP_CX_LEAN")) { if (atoi(env) == 0) lean = false; }   // test hook: the general kernel
+  if (!options().cx_lean) lean = false;                    // test hook (EPIHIP_CX_LEAN=0): the general kernel
   // lanes per row * 8 + chunks per lane; the heavy-tile kernel is the general one (three chunks per lane)
   const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused, lean);
   const int grp_heavy = np > 1 ? grp : pick_cx_shape(st.max_len, T, fused, false);
@@ -1302,7 +1302,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   a.tile_base = b->tile_base.as<uint32_t>();
   a.slab = b->d_slab;
   a.heavy_rows = 16384;
-  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }   // test hook
+  if (options().heavy_rows > 0) a.heavy_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   if (a.heavy_rows > 16384) a.heavy_rows = 16384;          // u16 pairs and the packed coverage halves: a base adds at most 2
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
@@ -1316,7 +1316,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   b->cx_last_ovf = (uint32_t)ovf_base;
   b->cx_last_np = np;
   b->cx_last_ctx_of_plane = a.ctx_of_plane;
-  EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, CX_WG, "CX tile kernel"));
+  EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, np == 1 && lean ? cx2_wg<true>() : CX_WG, "CX tile kernel"));
   a.nrows = b->n;
 #ifdef EPI_CHECK
   EPI_TRY(b->diag.ensure(256));
@@ -1538,10 +1538,9 @@ int epi_batch_cx_fetch_host(epi_batch *b, int32_t *const h_cols[6], void *stream
   int32_t *cols[6];
   for (int i = 0; i < 6; i++) cols[i] = d + (int64_t)i * nrow;
   EPI_TRY(epi_batch_cx_fetch_dev(b, cols, s));
-  for (int i = 0; i < 6; i++)
-    EPI_HIP(hipMemcpyAsync(h_cols[i], cols[i], (size_t)nrow * 4, hipMemcpyDeviceToHost, s));
-  EPI_HIP(hipStreamSynchronize(s));
-  return EPI_OK;
+  CopyPart parts[6];
+  for (int i = 0; i < 6; i++) parts[i] = {h_cols[i], cols[i], (size_t)nrow * 4};
+  return copy_parts_to_host(b->eng, parts, 6, s);
 }
 
 }  // extern "C"

@@ -3,29 +3,13 @@
 #include "common.hpp"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 namespace epi {
-
-static thread_local char g_err[512] = "";
-
-void set_error(const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
-int fail(int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
 
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap && p) return EPI_OK;
@@ -106,7 +90,6 @@ using namespace epi;
 
 extern "C" {
 
-const char *epi_last_error(void) { return g_err; }
 int epi_version(void) { return 100; }
 
 void epi_prof_enable(int on) { g_prof_on = on != 0; }
@@ -203,6 +186,7 @@ static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t
     }
     eng->pinned_bytes = chunk;
   }
+  for (int i = 0; i < 2; i++) EPI_HIP(hipEventSynchronize(eng->pinned_done[i]));   // (a device-to-host copy may have used them)
   size_t done = 0;
   int k = 0;
   while (done < bytes) {
@@ -216,6 +200,79 @@ static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t
   }
   return EPI_OK;                                           // (the caller synchronises the copy stream once, after all columns)
 }
+
+}  // extern "C"
+
+namespace epi {
+
+static int ensure_staging(epi_engine *eng) {
+  const size_t chunk = 64u << 20;
+  if (!eng->pinned[0]) {
+    for (int i = 0; i < 2; i++) {
+      EPI_HIP(hipHostMalloc(&eng->pinned[i], chunk, hipHostMallocDefault));
+      EPI_HIP(hipEventCreateWithFlags(&eng->pinned_done[i], hipEventDisableTiming));
+    }
+    eng->pinned_bytes = chunk;
+  }
+  return EPI_OK;
+}
+
+int copy_parts_to_host(epi_engine *eng, const CopyPart *parts, int nparts, hipStream_t s) {
+  const size_t piece = 8u << 20;                           // (the staging buffers hold 64 MiB each; 8 MiB pieces keep the
+                                                           // first copy-out early and the last one short)
+  struct Pending { void *dst; size_t len; int buf; };
+  Pending pend = {nullptr, 0, 0};
+  bool have = false, staged = false;
+  int k = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  auto drain = [&]() -> int {                              // wait for the piece in flight, copy it out of its staging buffer
+    if (!have) return EPI_OK;
+    EPI_HIP(hipEventSynchronize(ev[pend.buf]));
+    parallel_memcpy(pend.dst, eng->pinned[pend.buf], pend.len);
+    have = false;
+    return EPI_OK;
+  };
+  for (int i = 0; i < nparts; i++) {
+    const CopyPart &p = parts[i];
+    if (!p.bytes) continue;
+    if (is_pinned_host(p.dst)) { EPI_HIP(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, s)); continue; }
+    if (!staged) {
+      EPI_TRY(ensure_staging(eng));
+      for (int j = 0; j < 2; j++) EPI_HIP(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
+      staged = true;
+    }
+    for (size_t done = 0; done < p.bytes; done += piece) {
+      const size_t len = p.bytes - done < piece ? p.bytes - done : piece;
+      // buffer k was drained two pieces ago (drain() below runs before it is reused)
+      hipError_t e1 = hipMemcpyAsync(eng->pinned[k], static_cast<const char *>(p.src) + done, len, hipMemcpyDeviceToHost, s);
+      hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ev[k], s) : e1;
+      int rc = drain();                                    // the previous piece leaves its buffer while this one is on the link
+      if (e2 != hipSuccess || rc != EPI_OK) {
+        (void)hipStreamSynchronize(s);
+        for (int j = 0; j < 2; j++) if (ev[j]) (void)hipEventDestroy(ev[j]);
+        return rc != EPI_OK ? rc : fail(EPI_ERR_HIP, "device to host copy failed: %s", hipGetErrorName(e2));
+      }
+      pend = {static_cast<char *>(p.dst) + done, len, k};
+      have = true;
+      k ^= 1;
+    }
+  }
+  int rc = drain();
+  hipError_t e = hipStreamSynchronize(s);
+  for (int j = 0; j < 2; j++) if (ev[j]) (void)hipEventDestroy(ev[j]);
+  if (rc != EPI_OK) return rc;
+  if (e != hipSuccess) return fail(EPI_ERR_HIP, "device to host copy failed: %s", hipGetErrorName(e));
+  return EPI_OK;
+}
+
+int copy_to_host(epi_engine *eng, void *h_dst, const void *d_src, size_t bytes, hipStream_t s) {
+  const CopyPart p = {h_dst, d_src, bytes};
+  return copy_parts_to_host(eng, &p, 1, s);
+}
+
+}  // namespace epi
+
+extern "C" {
 
 int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const int32_t *rname,
                      const int32_t *strand, const int32_t *start, int64_t n, epi_batch **out) {

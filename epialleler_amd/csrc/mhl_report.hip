@@ -1431,8 +1431,7 @@ static void launch_mhl_tiles_wg(int g, int nt, hipStream_t s, const MhlArgs &a) 
 
 template <class ST>
 static void launch_mhl_tiles(int g, int nt, hipStream_t s, const MhlArgs &a) {
-  static int wg_env = -1;                                  // EPIHIP_MHL_WG=256/512 forces one (tests, A/B runs)
-  if (wg_env < 0) { wg_env = 0; if (const char *env = getenv("EPIHIP_MHL_WG")) { const int v = atoi(env); if (v == 256 || v == 512) wg_env = v; } }
+  const int wg_env = options().mhl_wg;                     // EPIHIP_MHL_WG=256/512 forces one (tests, A/B runs)
   const int wg = wg_env ? wg_env : (a.multi ? MHL_WG : MHL_WG_SHORT);
   if (wg == 256) launch_mhl_tiles_wg<256, ST>(g, nt, s, a); else launch_mhl_tiles_wg<512, ST>(g, nt, s, a);
 }
@@ -1451,8 +1450,7 @@ static void launch_mhl_heavy(int g, uint32_t nheavy, uint32_t nchunks, hipStream
 
 // lanes per row in the tile kernel (as pick_cx_group)
 static int pick_mhl_tile_group(int32_t max_len) {
-  const char *env = getenv("EPIHIP_MHL_TILE_GROUP");
-  if (env) { int g = atoi(env); if (g == 8 || g == 16 || g == 32 || g == 64) return g; }
+  { const int g = options().mhl_tile_group; if (g == 8 || g == 16 || g == 32 || g == 64) return g; }   // EPIHIP_MHL_TILE_GROUP
   const int slice = (max_len < MHL_T ? max_len : MHL_T) + 3;
   const int nd = (slice + 3) / 4;
   int g = 8;
@@ -1464,10 +1462,10 @@ static int pick_mhl_tile_group(int32_t max_len) {
 // read wherever it starts inside its first 16 bytes; 0 = the batch has longer reads than 64 lanes cover (or
 // EPIHIP_MHL_MULTI is set): k_mhl_rows_multi.  Returned as G*8 + C.
 static int pick_mhl_group(int32_t max_len) {
-  if (getenv("EPIHIP_MHL_MULTI")) return 0;
-  if (const char *env = getenv("EPIHIP_MHL_GROUP")) {                      // "G,C" for A/B runs; must cover the reads
-    int g = 0, c = 0;
-    if (sscanf(env, "%d,%d", &g, &c) == 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && c >= 2 && c <= 4 &&
+  if (options().mhl_multi) return 0;
+  if (options().mhl_group_g > 0) {                                         // EPIHIP_MHL_GROUP="G,C" for A/B runs; must cover the reads
+    const int g = options().mhl_group_g, c = options().mhl_group_c;
+    if ((g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && c >= 2 && c <= 4 &&
         (int64_t)g * 16 * c >= (int64_t)max_len + 15)
       return g * 8 + c;
   }
@@ -1528,8 +1526,7 @@ static void launch_mhl_fused(int gc, int nt, hipStream_t s, const MhlFArgs &a) {
 static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, double max_oo, hipStream_t s,
                             int64_t *nrow_out, bool *done) {
   *done = false;
-  static int enabled = -1;                                 // test hook: EPIHIP_MHL_FUSED=0 keeps every batch on the two-kernel path
-  if (enabled < 0) { enabled = 1; if (const char *env = getenv("EPIHIP_MHL_FUSED")) enabled = atoi(env) != 0; }
+  const int enabled = options().mhl_fused;                 // test hook: EPIHIP_MHL_FUSED=0 keeps every batch on the two-kernel path
   if (!enabled || !b->shared_keys.empty()) return EPI_OK;
   uint32_t k = 0;
   for (uint32_t c : {2u, 6u, 7u}) if (ctx_mask == ((1u << c) | (1u << (c + 8)))) k = c;
@@ -1540,7 +1537,7 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   bool nt_hinted = false;                                  // (a remembered tile count is verified at the synchronisation below)
   EPI_TRY(build_tiles(b, s, T, &st, &nt, &nt_hinted));
   const int gc = pick_mhl_group(st.max_len);
-  if (gc == 0 || getenv("EPIHIP_MHL_GROUP")) return EPI_OK;  // reads longer than one block of lanes: wavefront-per-read path
+  if (gc == 0 || options().mhl_group_g != 0) return EPI_OK;  // reads longer than one block of lanes: wavefront-per-read path
   b->last_ntiles = nt;
   if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; *done = true; return EPI_OK; }
   // u32 LDS sums while 255 rows of the largest possible value stay below 2^31 (h <= read length)
@@ -1554,7 +1551,7 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc layout as in the CX report: [1] cursor, [2] rows, [3] deep tiles
   if (!b->mhlf_slot) b->mhlf_slot = T / 8;
   uint32_t slot = b->mhlf_slot > 2u * T ? 2u * T : b->mhlf_slot;
-  if (const char *env = getenv("EPIHIP_MHL_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * T) slot = (uint32_t)v; }   // test hook
+  if (options().mhl_slot >= 0 && options().mhl_slot <= 2 * T) slot = (uint32_t)options().mhl_slot;   // test hook (EPIHIP_MHL_SLOT)
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;
   size_t ovf_base = (size_t)nt * slot;
   for (;;) {
@@ -1590,7 +1587,7 @@ static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmi
   a.tile_base = b->tile_base.as<uint32_t>();
   a.deep = b->misc.as<uint32_t>() + 3;
   a.max_rows = 255;
-  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0 && v < 255) a.max_rows = v; }   // test hook
+  if (options().heavy_rows > 0 && options().heavy_rows < 255) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;
   EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, MHLF_WG, "lMHL tile kernel"));
@@ -1718,7 +1715,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   a.tile_nrow = b->tile_nrow.as<uint32_t>();
   a.tile_base = b->tile_base.as<uint32_t>();
   a.heavy_rows = 16384;
-  if (const char *env = getenv("EPIHIP_HEAVY_ROWS")) { const int v = atoi(env); if (v > 0) a.heavy_rows = v; }
+  if (options().heavy_rows > 0) a.heavy_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   if (a.heavy_rows > 32767) a.heavy_rows = 32767;          // k_mhl_tiles' packed u16 counters: a base adds at most 2 (the
                                                            // CX kernels cap at 16384, cx_report.hip)
   const int heavy_rows_base = a.heavy_rows;
@@ -1738,7 +1735,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   // (pos,strand) cells of a tile a row; the slot doubles for the next call when 1/8 of the rows outgrew it
   if (!b->mhl_slot) b->mhl_slot = MHL_T / 8;
   uint32_t slot = b->mhl_slot > 2u * MHL_T ? 2u * MHL_T : b->mhl_slot;
-  if (const char *env = getenv("EPIHIP_MHL_SLOT")) { const int v = atoi(env); if (v >= 0 && v <= 2 * MHL_T) slot = (uint32_t)v; }
+  if (options().mhl_slot >= 0 && options().mhl_slot <= 2 * MHL_T) slot = (uint32_t)options().mhl_slot;   // test hook (EPIHIP_MHL_SLOT)
   while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;   // row indices are u32
   size_t ovf_base = (size_t)nt * slot;
   for (;;) {
@@ -1801,7 +1798,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
     const unsigned long long vmax = nrS(hcap) > 1 ? nrS(hcap) : 1;
     const unsigned long long narrow_rows = ((1ull << 31) - 1) / (vmax + 1);
     bool narrow = narrow_rows >= 512;
-    if (const char *env = getenv("EPIHIP_MHL_SUMS")) narrow = narrow && atoi(env) == 32;   // "64" forces the wide kernel
+    if (options().mhl_sums) narrow = narrow && options().mhl_sums == 32;   // EPIHIP_MHL_SUMS=64 forces the wide kernel
     a.heavy_rows = heavy_rows_base;
     if (narrow && (unsigned long long)a.heavy_rows > narrow_rows) a.heavy_rows = (int)narrow_rows;
     a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
@@ -1929,11 +1926,13 @@ int epi_batch_mhl_fetch_dev(epi_batch *b, int32_t *const d_icols[5], double *con
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   const unsigned nb = (unsigned)((b->last_ntiles + 3) / 4);
+  prof_begin("gather", s);
   hipLaunchKernelGGL(k_mhl_gather, dim3(nb), dim3(256), 0, s, b->tiles.as<Tile>(), b->tile_out.as<uint32_t>(),
                      b->tile_nrow.as<uint32_t>(), b->tile_base.as<uint32_t>(), b->last_ntiles, b->pool_key.as<uint32_t>(),
                      b->pool_a.as<uint32_t>(), b->pool_d.as<unsigned long long>(), b->pool_e.as<unsigned long long>(),
                      b->pool_f.as<unsigned long long>(), d_icols[0], d_icols[1],
                      d_icols[2], d_icols[3], d_icols[4], d_dcols[0], d_dcols[1]);
+  prof_end("gather", s);
   EPI_HIP(hipGetLastError());
   return EPI_OK;
 }
@@ -1952,10 +1951,10 @@ int epi_batch_mhl_fetch_host(epi_batch *b, int32_t *const h_icols[5], double *co
   int32_t *ic[5];
   for (int i = 0; i < 5; i++) ic[i] = di + (int64_t)i * nrow;
   EPI_TRY(epi_batch_mhl_fetch_dev(b, ic, dc, s));
-  for (int i = 0; i < 5; i++) EPI_HIP(hipMemcpyAsync(h_icols[i], ic[i], (size_t)nrow * 4, hipMemcpyDeviceToHost, s));
-  for (int i = 0; i < 2; i++) EPI_HIP(hipMemcpyAsync(h_dcols[i], dc[i], (size_t)nrow * 8, hipMemcpyDeviceToHost, s));
-  EPI_HIP(hipStreamSynchronize(s));
-  return EPI_OK;
+  CopyPart parts[7];
+  for (int i = 0; i < 5; i++) parts[i] = {h_icols[i], ic[i], (size_t)nrow * 4};
+  for (int i = 0; i < 2; i++) parts[5 + i] = {h_dcols[i], dc[i], (size_t)nrow * 8};
+  return copy_parts_to_host(b->eng, parts, 7, s);
 }
 
 }  // extern "C"

@@ -319,8 +319,7 @@ bool make_field_lut(const char *const cls[4], ClassLut *out) {
 }
 
 static int pick_group(const epi_batch *b) {
-  const char *env = getenv("EPIHIP_GROUP");
-  if (env) { int g = atoi(env); if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }
+  { const int g = options().pr_group; if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) return g; }   // EPIHIP_GROUP
   // lanes per read: just enough that PR_UN chunks per lane cover a typical read in one pass (measured
   // fastest on PE150: 2 lanes x 10 chunks; one lane per read loses to uncoalesced access)
   const int64_t mean = b->n > 0 ? b->nbytes / b->n : 0;
@@ -338,8 +337,7 @@ static int launch_per_read_wide(epi_batch *b, const ClassLut &F, const ThrParams
   const int64_t chunks = mean / 16 + 2;
   int g = 2;                                              // short reads: fewer lanes per read (a 50-byte read is 4-5 chunks)
   while (g < 64 && (int64_t)g * PW_NU < chunks) g <<= 1;
-  static int rpg_env = 0;
-  if (!rpg_env) { rpg_env = PW_RPG; if (const char *env = getenv("EPIHIP_PR_RPG")) { const int v = atoi(env); if (v >= 2 && v <= 4) rpg_env = v; } }
+  const int rpg_env = options().pr_rpg >= 2 && options().pr_rpg <= 4 ? options().pr_rpg : PW_RPG;   // EPIHIP_PR_RPG
   const int rpg = g == 2 ? 2 : (g == 4 ? 4 : rpg_env);    // lane q of a group decides read q: RPG <= G
   const int64_t rows_per_wg = 4 * (int64_t)rpg * (64 / g);
   const unsigned nb = (unsigned)((b->n + rows_per_wg - 1) / rows_per_wg);
@@ -363,9 +361,7 @@ static int launch_per_read(epi_batch *b, const Luts &L, const ThrParams &prm, in
                            hipStream_t s, const ClassLut *F = nullptr) {
   if (b->n == 0) return EPI_OK;
   {
-    static int wide = -1;
-    if (wide < 0) { wide = 1; if (const char *env = getenv("EPIHIP_PR_WIDE")) wide = atoi(env) != 0; }
-    if (F && wide) {
+    if (F && options().pr_wide) {                         // EPIHIP_PR_WIDE=0: the 2-lane layout for every call
       EPI_TRY(fetch_row_stats(b, s));                     // the longest read (known since ingest)
       if (!b->h_stats.bad_len && b->h_stats.max_len < 65536 && b->nbytes >= 16) return launch_per_read_wide<BETA>(b, *F, prm, d_pass, d_beta, s);
     }

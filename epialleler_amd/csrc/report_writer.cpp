@@ -33,7 +33,8 @@ inline char *put_i32(char *p, int32_t v) {
 inline char *put_f64(char *p, double x) {
   if (isnan(x)) return p;                                  // NA / NaN: na = ""
   if (isinf(x)) { if (x < 0) *p++ = '-'; memcpy(p, "Inf", 3); return p + 3; }
-  if (x == (double)(int64_t)x && fabs(x) < 1e15) {         // integral values print without a fraction (as %.15g does)
+  if (fabs(x) < 1e15 && x == (double)(int64_t)x) {         // integral values print without a fraction (as %.15g does);
+                                                           // the magnitude test comes first: the cast is undefined at 2^63 and beyond
     int64_t v = (int64_t)x;
     uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
     if (v < 0) *p++ = '-';

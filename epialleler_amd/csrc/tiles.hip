@@ -259,8 +259,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   EPI_TRY(check_grid(nb, TB_THREADS, "tile index"));
   int slot = -1;
   for (int i = 0; i < 4; i++) if (b->tile_hint_T[i] == T) slot = i;
-  static int use_hint = -1;                                // EPIHIP_TILE_HINT=0: every call counts, scans and asks (A/B runs, tests)
-  if (use_hint < 0) { use_hint = 1; if (const char *env = getenv("EPIHIP_TILE_HINT")) use_hint = atoi(env) != 0; }
+  const int use_hint = options().tile_hint;                // EPIHIP_TILE_HINT=0: every call counts, scans and asks (A/B runs, tests)
   if (use_hint && hinted && slot >= 0 && b->tile_hint_lmax[slot] == lmax) {
     // The tile count and the per-block offsets are functions of the batch's rows and T alone: with those of an earlier
     // call the table is allocated up front and filled by ONE pass that verifies them block by block; the caller

@@ -14,6 +14,7 @@
 // preprocessed object, therefore move the bytes over PCIe one time.  `seqxm_xptr` keeps its type and meaning.
 #include <Rcpp.h>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "epihip.h"
@@ -28,29 +29,42 @@ void check(int rc) { if (rc != EPI_OK) Rcpp::stop("%s", epi_last_error()); }
 // The resident batch of `df`: cached handle, else upload from the producer's pinned SoA (`seqxm_soa_xptr`, set by the
 // rcpp_read_bam_* shims below), else gather the strings behind `seqxm_xptr` in row order and upload those.
 Resident &resident_of(Rcpp::DataFrame &df) {
-  SEXP cached = df.attr("seqxm_hip_xptr");
-  if (cached != R_NilValue) return *Rcpp::XPtr<Resident>(cached);
-  Rcpp::IntegerVector rname = df["rname"], strand = df["strand"], start = df["start"];
+  Rcpp::IntegerVector rname = df["rname"], strand = df["strand"], start = df["start"], templid = df["templid"];
   const R_xlen_t n = rname.size();
+  // the rows this call is about: the cached batch is reused only if it was built from exactly these (ADVICE round 2:
+  // a by-reference setorder / setkey or a subset that kept its attributes would otherwise be served the old rows)
+  const epihip_shim::RowOrder order = epihip_shim::row_order_of(templid.begin(), (int64_t)n);
+  SEXP cached = df.attr("seqxm_hip_xptr");
+  if (cached != R_NilValue) {
+    Rcpp::XPtr<Resident> xp(cached);
+    if (xp->order == order) return *xp;
+    df.attr("seqxm_hip_xptr") = R_NilValue;                // stale: rebuild below (the old batch goes with its finalizer)
+  }
   Resident *r = nullptr;
   SEXP soa = df.attr("seqxm_soa_xptr");
   Rcpp::checkUserInterrupt();
   try {
     if (soa != R_NilValue) {
-      // rows of the producer's batch are in table order as long as the table was not re-ordered or subset
       Rcpp::XPtr<epihip_shim::TemplatesGuard> tg(soa);
-      if (tg->t.n != (int64_t)n) Rcpp::stop("the preprocessed table was subset after reading: call preprocessBam again");
-      r = Resident::upload(tg->t.xm, tg->t.off, rname.begin(), strand.begin(), start.begin(), n);
+      if (order.identity && tg->t.n == (int64_t)n) {
+        // rows of the producer's batch are the table's rows: upload in place (pinned source, no staging copy)
+        r = Resident::upload(tg->t.xm, tg->t.off, rname.begin(), strand.begin(), start.begin(), n);
+      } else {
+        // re-ordered / subset table: row x is template templid[x], as seqxm->at(templid[x]) is for the reference
+        epihip_shim::Soa s;
+        epihip_shim::gather_soa(tg->t, templid.begin(), (int64_t)n, s, []() { Rcpp::checkUserInterrupt(); });
+        r = Resident::upload(s.xm.data(), s.off.data(), rname.begin(), strand.begin(), start.begin(), n);
+      }
     } else {
       Rcpp::XPtr<std::vector<std::string>> seqxm((SEXP)df.attr("seqxm_xptr"));
-      Rcpp::IntegerVector templid = df["templid"];
       epihip_shim::Soa s;
       epihip_shim::gather_rows(*seqxm, templid.begin(), (int64_t)n, s, []() { Rcpp::checkUserInterrupt(); });
       r = Resident::upload(s.xm.data(), s.off.data(), rname.begin(), strand.begin(), start.begin(), n);
     }
-  } catch (const std::runtime_error &e) {
+  } catch (const std::exception &e) {
     Rcpp::stop("%s", e.what());
   }
+  r->order = order;
   Rcpp::XPtr<Resident> xp(r, true);                      // finalizer: ~Resident -> epi_batch_free
   df.attr("seqxm_hip_xptr") = xp;
   Rcpp::checkUserInterrupt();
@@ -69,15 +83,21 @@ void set_factors(Rcpp::DataFrame &res, Rcpp::IntegerVector &rname, Rcpp::Integer
   col_context.attr("levels") = Rcpp::CharacterVector::create("NA1", "CHH", "NA3", "NA4", "NA5", "CHG", "CG");
 }
 
-Rcpp::DataFrame cx_frame(const epi_cx_table &t, Rcpp::DataFrame &df) {
-  Rcpp::IntegerVector rname = df["rname"], strand = df["strand"];
-  auto col = [&](const int32_t *p) { return Rcpp::IntegerVector(p, p + t.nrow); };
-  Rcpp::DataFrame res = Rcpp::DataFrame::create(
-      Rcpp::Named("rname") = col(t.rname), Rcpp::Named("strand") = col(t.strand), Rcpp::Named("pos") = col(t.pos),
-      Rcpp::Named("context") = col(t.context), Rcpp::Named("meth") = col(t.meth), Rcpp::Named("unmeth") = col(t.unmeth));
-  set_factors(res, rname, strand);
-  return res;
-}
+// the six columns of a CX table as R vectors the library fills in place (src/rcpp_cx_report.cpp:133-140)
+struct CxColumns {
+  Rcpp::IntegerVector v[6];
+  void operator()(int64_t nrow, int32_t *(&cols)[6]) {
+    for (int i = 0; i < 6; i++) { v[i] = Rcpp::IntegerVector(Rcpp::no_init((R_xlen_t)nrow)); cols[i] = v[i].begin(); }
+  }
+  Rcpp::DataFrame frame(Rcpp::DataFrame &df) {
+    Rcpp::IntegerVector rname = df["rname"], strand = df["strand"];
+    Rcpp::DataFrame res = Rcpp::DataFrame::create(
+        Rcpp::Named("rname") = v[0], Rcpp::Named("strand") = v[1], Rcpp::Named("pos") = v[2],
+        Rcpp::Named("context") = v[3], Rcpp::Named("meth") = v[4], Rcpp::Named("unmeth") = v[5]);
+    set_factors(res, rname, strand);
+    return res;
+  }
+};
 
 }  // namespace
 
@@ -110,28 +130,30 @@ std::vector<double> rcpp_get_xm_beta(Rcpp::DataFrame &df, const std::string ctx_
 Rcpp::DataFrame rcpp_cx_report(Rcpp::DataFrame &df, Rcpp::LogicalVector &pass, const std::string ctx) {
   Resident &r = resident_of(df);
   if (pass.size() != r.n) Rcpp::stop("pass must have one entry per row");
-  epihip_shim::CxTableGuard g;
+  CxColumns cols;
   // an R logical vector is int32 with NA = INT_MIN; the ABI treats any non-zero value as TRUE (:118)
-  check(epi_batch_cx_report(r.batch, pass.begin(), ctx.c_str(), &g.t));
+  try { epihip_shim::cx_report_into(r.batch, pass.begin(), ctx.c_str(), std::ref(cols)); } catch (const std::exception &e) { Rcpp::stop("%s", e.what()); }
   Rcpp::checkUserInterrupt();
-  return cx_frame(g.t, df);
+  return cols.frame(df);
 }
 
 // [[Rcpp::export]]
 Rcpp::DataFrame rcpp_mhl_report(Rcpp::DataFrame &df, const std::string ctx, int hmax, const int hmin,
                                 const double max_ooctx_meth_frac) {
   Resident &r = resident_of(df);
-  epihip_shim::MhlTableGuard g;
-  check(epi_batch_mhl_report(r.batch, ctx.c_str(), hmax, hmin, max_ooctx_meth_frac, &g.t));
+  Rcpp::IntegerVector iv[5];
+  Rcpp::NumericVector dv[2];
+  auto alloc = [&](int64_t nrow, int32_t *(&ic)[5], double *(&dc)[2]) {
+    for (int i = 0; i < 5; i++) { iv[i] = Rcpp::IntegerVector(Rcpp::no_init((R_xlen_t)nrow)); ic[i] = iv[i].begin(); }
+    for (int i = 0; i < 2; i++) { dv[i] = Rcpp::NumericVector(Rcpp::no_init((R_xlen_t)nrow)); dc[i] = dv[i].begin(); }
+  };
+  try { epihip_shim::mhl_report_into(r.batch, ctx.c_str(), hmax, hmin, max_ooctx_meth_frac, alloc); } catch (const std::exception &e) { Rcpp::stop("%s", e.what()); }
   Rcpp::checkUserInterrupt();
-  const epi_mhl_table &t = g.t;
   Rcpp::IntegerVector rname = df["rname"], strand = df["strand"];
-  auto icol = [&](const int32_t *p) { return Rcpp::IntegerVector(p, p + t.nrow); };
-  auto dcol = [&](const double *p) { return Rcpp::NumericVector(p, p + t.nrow); };
   Rcpp::DataFrame res = Rcpp::DataFrame::create(
-      Rcpp::Named("rname") = icol(t.rname), Rcpp::Named("strand") = icol(t.strand), Rcpp::Named("pos") = icol(t.pos),
-      Rcpp::Named("context") = icol(t.context), Rcpp::Named("coverage") = icol(t.coverage),
-      Rcpp::Named("length") = dcol(t.length), Rcpp::Named("lmhl") = dcol(t.lmhl));
+      Rcpp::Named("rname") = iv[0], Rcpp::Named("strand") = iv[1], Rcpp::Named("pos") = iv[2],
+      Rcpp::Named("context") = iv[3], Rcpp::Named("coverage") = iv[4],
+      Rcpp::Named("length") = dv[0], Rcpp::Named("lmhl") = dv[1]);
   set_factors(res, rname, strand);
   return res;
 }
@@ -148,11 +170,13 @@ Rcpp::DataFrame rcpp_cytosine_report(Rcpp::DataFrame &df, const std::string ctx_
                                      const unsigned int min_n_ctx, const double min_ctx_meth_frac,
                                      const double max_ooctx_meth_frac, const std::string ctx) {
   Resident &r = resident_of(df);
-  epihip_shim::CxTableGuard g;
-  check(epi_batch_cytosine_report(r.batch, ctx_meth.c_str(), ctx_unmeth.c_str(), ooctx_meth.c_str(), ooctx_unmeth.c_str(),
-                                  min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac, ctx.c_str(), nullptr, &g.t));
+  CxColumns cols;
+  try {
+    epihip_shim::cytosine_report_into(r.batch, ctx_meth.c_str(), ctx_unmeth.c_str(), ooctx_meth.c_str(), ooctx_unmeth.c_str(),
+                                      min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac, ctx.c_str(), nullptr, std::ref(cols));
+  } catch (const std::exception &e) { Rcpp::stop("%s", e.what()); }
   Rcpp::checkUserInterrupt();
-  return cx_frame(g.t, df);
+  return cols.frame(df);
 }
 
 // ---- the readers (src/rcpp_read_bam.cpp:19-579) over the library's producer ------------------------------------------

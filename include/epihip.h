@@ -171,6 +171,16 @@ int epi_batch_cytosine_report(epi_batch *b, const char *ctx_meth, const char *ct
                               double max_ooctx_meth_frac, const char *ctx, int32_t *pass_out /* host, may be NULL */,
                               epi_cx_table *out);
 int epi_batch_mhl_report(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, epi_mhl_table *out);
+/* The same reports in two steps, for a binding that owns the result vectors (R's IntegerVector / NumericVector,
+ * src/rcpp_cx_report.cpp:133-140, src/rcpp_mhl_report.cpp:200-208): *_begin runs the report on the engine's stream and
+ * returns the row count; the caller allocates its columns and epi_batch_cx_fetch_host / epi_batch_mhl_fetch_host (stream
+ * NULL) copy the table straight into them -- no library-owned table, no second host copy. */
+int epi_batch_cx_report_begin(epi_batch *b, const int32_t *pass /* host, may be NULL */, const char *ctx, int64_t *nrow_out);
+int epi_batch_cytosine_report_begin(epi_batch *b, const char *ctx_meth, const char *ctx_unmeth, const char *ooctx_meth,
+                                    const char *ooctx_unmeth, uint32_t min_n_ctx, double min_ctx_meth_frac,
+                                    double max_ooctx_meth_frac, const char *ctx, int32_t *pass_out /* host, may be NULL */,
+                                    int64_t *nrow_out);
+int epi_batch_mhl_report_begin(epi_batch *b, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac, int64_t *nrow_out);
 /* the lazily created engine the host-pointer entry points use (device EPIHIP_DEVICE, default 0) */
 int epi_default_engine(epi_engine **out);
 
@@ -307,6 +317,10 @@ void epi_prof_enable(int on);
 /* name: "cx_tiles", "threshold", "mhl_tiles", ...; returns accumulated ms and launch count since reset */
 int epi_prof_get(const char *name, double *ms_total, int64_t *launches);
 void epi_prof_reset(void);
+
+/* Test hook.  The library's environment switches (EPIHIP_*: result-neutral hooks that steer a call onto a rarely
+ * taken path) are read once per process; this re-reads them. */
+void epi_options_reload(void);
 
 #ifdef __cplusplus
 }

@@ -304,16 +304,30 @@ def test_deep_pileup_and_many_rnames(ea):
     check_all(ea, t, contexts=("CG",))
 
 
-def test_heavy_tiles_are_split(ea, monkeypatch):
+@pytest.fixture
+def hook_env(ea, monkeypatch):
+    """Sets EPIHIP_* test hooks inside this process: the library reads its switches once, so it is told to re-read
+    them after every change (epi_options_reload) and once more when the environment has been restored."""
+    lib = ea._lib.load()
+
+    def setenv(name, value):
+        monkeypatch.setenv(name, value)
+        lib.epi_options_reload()
+    yield setenv
+    monkeypatch.undo()
+    lib.epi_options_reload()
+
+
+def test_heavy_tiles_are_split(ea, hook_env):
     """Ultra-deep tiles are set aside and split over many workgroups (k_cx_heavy); force that path on small data."""
-    monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "300")
+    hook_env("EPIHIP_HEAVY_ROWS", "300")
     rng = np.random.default_rng(31)
     t = synth_np.random_templates(rng, 5000, 50, 400, 2, 60)            # two pile-ups, every tile heavy
     check_all(ea, t, mhl=True, contexts=("CG", "CX"))
     t = synth_np.random_templates(rng, 3000, 0, 700, 3, 9000)           # a mix of heavy and ordinary tiles
     check_all(ea, t, mhl=True, contexts=("CG", "CX"))
     check_all(ea, H.bam("amplicon010meth.bam"), mhl=True, contexts=("CG", "CX"))
-    monkeypatch.setenv("EPIHIP_HEAVY_ROWS", "70")
+    hook_env("EPIHIP_HEAVY_ROWS", "70")
     check_all(ea, H.bam("amplicon010meth.bam"), mhl=True, contexts=("CG",))
 
 

@@ -128,6 +128,23 @@ def test_write_report_na_and_many_rows(tmp_path):
     assert (tmp_path / "pat.tsv").read_text() == "strand\tbeta\tpattern\n+\t\t00AB\n-\t0.25\t\n"
 
 
+def test_write_report_double_format(tmp_path):
+    """The double formatting of the native writer, pinned against Python's `%.15g` (what round 1's writer produced; the
+    reference holds no written-file fixture, so data.table::fwrite's own text is parity unpinned): huge and tiny
+    magnitudes, the 1e15 switch from integer to %.15g form, negative zero (prints as 0), a repeating fraction."""
+    import epialleler_amd as ea
+    vals = np.asarray([1e300, -1e300, 2.0 ** 63, -2.0 ** 63, 1e15, 1e15 - 1, -(1e15 - 1), 999999999999999.5, 1e-300, 1.0 / 3.0,
+                       -0.0, 0.0, 123456789.125, 2.5e-7, 1e16, 4.0, -17.0], np.float64)
+    rep = ea.Report({"pos": np.arange(vals.size, dtype=np.int32), "lmhl": vals})
+    p = tmp_path / "f.tsv"
+    ea.writeReport(rep, str(p), nthreads=2)
+    lines = p.read_text().split("\n")[1:-1]
+    assert len(lines) == vals.size
+    for i, v in enumerate(vals):
+        want = "0" if v == 0 else "%.15g" % v
+        assert lines[i] == "%d\t%s" % (i, want), (i, lines[i], want)
+
+
 def test_no_timing_switches_in_the_product_library():
     """Timing builds (phases skipped: wrong results by design) are a compile-time make target; the shipped library
     must not contain the environment switches of round 1."""

@@ -199,3 +199,25 @@ def test_threads_give_the_same_table_on_a_generated_bam(tmp_path):
         else:
             for k in ref:
                 assert np.array_equal(ref[k], cur[k]), (k, nt, win)
+
+
+def test_host_columns_outlive_the_processed_bam(ea):
+    """The numpy columns of preprocessBam() own the producer's buffers: keeping `bam.host["xm"]`
+    after the ProcessedBam is collected must not read freed (or hipHostFree'd) memory."""
+    import gc
+    path = os.path.join(BAM, "capture.bam")
+    want = ea.preprocessBam(path)
+    ref = {k: np.array(v) for k, v in want.host.items()}
+    xm = ea.preprocessBam(path).host["xm"]               # the ProcessedBam is garbage right away
+    cols = ea.preprocessBam(path).host
+    gc.collect()
+    junk = [ea.preprocessBam(path) for _ in range(3)]    # allocator churn over whatever was freed
+    del junk
+    gc.collect()
+    assert np.array_equal(xm, ref["xm"])
+    for k in ref:
+        assert np.array_equal(cols[k], ref[k]), k
+    sl = xm[100:200]
+    del xm
+    gc.collect()
+    assert np.array_equal(sl, ref["xm"][100:200])
