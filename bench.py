@@ -12,13 +12,17 @@ the tile index, the LDS-histogram tile kernel with the majority rule, and the or
 gather into the six output columns (which stay in HBM, as the input does).  A "read"
 is one template row (a merged read pair).
 
+The workload is SURVEY 8d's stream literally: starts uniform-random on the genome, sorted (on the device), L = 300.
 Besides the contract line's `value` (inputs resident in HBM) the N=1 line carries
   streamed   the same report with the batch starting in pinned host memory (upload + report), SURVEY 8d
   d2h        the report table copied to pinned host memory
-  cfg2u      the SURVEY-8d-conformant variant of the workload (uniform-random starts sorted on device,
-             ragged template lengths, a 50-byte 0xFB gap between the mates of every fourth template)
+  host_out   the report as a host binding (the R shim) gets it: table in host memory, one-call and two-step forms
+  sharded_1rank  the same step through the sharded driver on one rank: 14 forced shared tiles + a real RCCL all-reduce
+  cfg2g / cfg2u / cfg2p   the stream's effects apart: round 1/2's jittered-grid starts / ragged lengths and gapped
+             mates / one 20 000-row pile-up in the stream
   strong_cfg3  BASELINE config 3 (100 M templates in total, split over the N GPUs)
-and every N>1 run first checks, on a reduced-size stream, that the sharded table equals the single-GPU table.
+and every N>1 run first checks, on a reduced-size stream whose cuts lie inside chromosomes, that the sharded tables equal
+the single-GPU tables and that the shared-tile exchange really carried bytes.
 """
 import argparse
 import json
@@ -29,22 +33,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Streams (epialleler_amd/synth.py, csrc/synth.hip; one context track per chromosome position, depth 30):
+#   "uniform"  SURVEY 8d's literal wording: starts uniform-random on the chromosome, then sorted (on the device); every
+#              template exactly L bytes.  The headline stream since round 3.
+#   "grid"     round 1/2's headline stream: start_j = 1 + floor(j G / N) + jitter (sorted by construction)
+#   "ragged"   uniform starts, template lengths 0.8-1.2 L, a 50-byte 0xFB gap between the mates of every fourth template
+#   pileup     (uniform) + `pileup` consecutive rows that all start at one position: an amplicon hot spot in WGS-like data
 WORKLOADS = {
     # name: (rows per GPU, template bytes, report)
-    "cfg2": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG",
-                 desc="simulateBam-like 10M PE150 templates (L=300, depth 30, 4 chr), generateCytosineReport defaults "
-                      "(threshold.reads=TRUE, CG)"),
-    "cfg2u": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", uniform=True,
-                  desc="as cfg2 with uniform-random starts (sorted on device), template lengths 240-360 and a 50-byte "
-                       "0xFB gap in every fourth template"),
-    "cfg2n": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CG",
+    "cfg2": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="uniform",
+                 desc="simulateBam-like 10M PE150 templates (L=300 fixed, uniform-random starts sorted on device, depth 30), "
+                      "generateCytosineReport defaults (threshold.reads=TRUE, CG)"),
+    "cfg2g": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="grid",
+                  desc="as cfg2 on round 1/2's stream: jittered grid starts instead of uniform-random ones"),
+    "cfg2u": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="ragged",
+                  desc="as cfg2 with template lengths 240-360 and a 50-byte 0xFB gap in every fourth template"),
+    "cfg2p": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="uniform", pileup=20_000,
+                  desc="as cfg2 with one 20 000-row pile-up (all rows starting at one position) in the middle of the stream"),
+    "cfg2n": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CG", stream="uniform",
                   desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE): SURVEY 8d's un-thresholded config 2"),
-    "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX",
+    "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX", stream="uniform",
                    desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE, report.context='CX')"),
-    "cfg3": dict(rows=100_000_000, strong=True, read_len=300, kind="cx", threshold=True, report_context="CG",
+    "cfg3": dict(rows=100_000_000, strong=True, read_len=300, kind="cx", threshold=True, report_context="CG", stream="uniform",
                  desc="100M PE150 templates in total (split over the GPUs), generateCytosineReport defaults"),
-    "cfg4": dict(rows=50_000_000, read_len=300, kind="mhl", desc="50M PE150 templates, generateMhlReport defaults"),
-    "cfg5": dict(rows=5_000_000, read_len=10000, kind="cx", threshold=False, report_context="CG",
+    "cfg4": dict(rows=50_000_000, read_len=300, kind="mhl", stream="uniform", desc="50M PE150 templates, generateMhlReport defaults"),
+    "cfg4d": dict(rows=50_000_000, read_len=300, kind="mhl", stream="uniform", pileup=20_000,
+                  desc="as cfg4 with one 20 000-row pile-up in the middle of the stream"),
+    "cfg5": dict(rows=5_000_000, read_len=10000, kind="cx", threshold=False, report_context="CG", stream="uniform",
                  desc="5M long-read (10 kb) templates, generateCytosineReport(threshold.reads=FALSE)"),
     # the only throughput the reference publishes (vignettes/epialleleR.Rmd:172-176): BAM on disk -> CX report on disk
     "file": dict(rows=500_000, read_len=300, kind="file",
@@ -144,10 +159,23 @@ class Ctx:
         return int(t.item())
 
 
-def make_batch(cx, wl, rows, L, n_total):
-    if wl.get("uniform"):
-        return cx.synth.generate_device_uniform(n_total=n_total, mean_len=L, row_first=cx.rank * rows, n=rows, device=cx.local)
-    return cx.synth.generate_device(n_total=n_total, read_len=L, row_first=cx.rank * rows, n=rows, device=cx.local)
+def n_chr_for(world):
+    """Chromosomes of the synthetic genome.  SURVEY 8d: 4.  With 2 or 4 ranks (and 4 of the 7 cuts at 8) equal row ranges
+    of a 4-chromosome stream are cut exactly at chromosome boundaries: no tile is shared and the exchange step never
+    runs.  N > 1 therefore uses 3 chromosomes (same rows, bytes, depth per GPU): every cut lies inside a chromosome."""
+    return 4 if world == 1 else 3
+
+
+def make_batch(cx, wl, rows, L, n_total, seed=42):
+    kw = dict(n_total=n_total, n_chr=n_chr_for(cx.world), seed=seed, row_first=cx.rank * rows, n=rows, device=cx.local)
+    stream = wl.get("stream", "uniform")
+    if stream == "grid":
+        return cx.synth.generate_device(read_len=L, **kw)
+    if wl.get("pileup"):
+        kw["pileup"] = (n_total // 2 + 1234, int(wl["pileup"]))
+    if stream == "ragged":
+        return cx.synth.generate_device_uniform(mean_len=L, **kw)
+    return cx.synth.generate_device_uniform(mean_len=L, ragged=False, gap_every=0, **kw)
 
 
 def make_step(cx, wl, bam, eng, gather):
@@ -189,7 +217,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False):
     cx.lib.epi_prof_enable(0)
     dt = cx.max_over_ranks(dt)
     kernels = {}
-    for nm in (b"threshold", b"cx_tiles", b"cx_heavy", b"mhl_rows", b"mhl_tiles", b"tile_index", b"gather"):
+    for nm in (b"threshold", b"cx_tiles", b"cx_heavy", b"mhl_rows", b"mhl_tiles", b"mhl_deep", b"mhl_heavy", b"tile_index", b"gather"):
         m2, c2 = C.c_double(0), C.c_int64(0)
         cx.lib.epi_prof_get(nm, C.byref(m2), C.byref(c2))
         if c2.value:
@@ -207,19 +235,25 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False):
 
 
 def selfcheck(cx, n_total):
-    """N>1: the sharded table of a reduced-size stream, gathered on rank 0, must equal the single-GPU table of the
-    same stream (CX with thresholding, and lMHL).  Every rank raises on a mismatch."""
+    """N>1: the sharded tables of a reduced-size stream, gathered on rank 0, must equal the single-GPU tables of the
+    same stream (CX with thresholding, and lMHL), AND the exchange step must have run: the stream's cuts lie inside
+    chromosomes (n_chr_for), so every cut has shared tiles and the slab all-reduce carries bytes.  Every rank raises on a
+    mismatch or on an exchange of zero bytes."""
     torch, ea, D = cx.torch, cx.ea, cx.D
     rows = (n_total + cx.world - 1) // cx.world
     n_total = rows * cx.world
-    bam = cx.synth.generate_device(n_total=n_total, read_len=300, row_first=cx.rank * rows, n=rows, device=cx.local, seed=5)
+    wl = WORKLOADS["cfg2"]
+    bam = make_batch(cx, wl, rows, 300, n_total, seed=5)
     eng = D.HipShardEngine(bam)
     got_cx = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True, levels=bam.levels)
+    xb_cx = cx.sum_over_ranks(eng.last_exchange_bytes)
     got_mhl = D.sharded_mhl(eng, gather=True, levels=bam.levels)
+    xb_mhl = cx.sum_over_ranks(eng.last_exchange_bytes)
     ok = 1
     nrow = 0
     if cx.rank == 0:
-        whole = cx.synth.generate_device(n_total=n_total, read_len=300, device=cx.local, seed=5)
+        whole = cx.synth.generate_device_uniform(n_total=n_total, mean_len=300, n_chr=n_chr_for(cx.world), seed=5, device=cx.local,
+                                                 ragged=False, gap_every=0)
         ref_cx = ea.generateCytosineReport(whole, threshold_reads=True, report_context="CG", as_device=True)
         ref_mhl = ea.generateMhlReport(whole, as_device=True)
         ok = int(all(bool(torch.equal(ref_cx[k], got_cx[k])) for k in ref_cx) and
@@ -233,8 +267,12 @@ def selfcheck(cx, n_total):
     bam.close()
     if int(t.item()) != 1:
         raise SystemExit("selfcheck FAILED: sharded table differs from the single-GPU table (%d rows over %d ranks)" % (n_total, cx.world))
-    return {"rows_total": n_total, "cx_rows": nrow, "ok": True, "what": "sharded CX (thresholded) and lMHL tables, gathered "
-            "on rank 0 over %s, bit-equal to the single-GPU tables of the same stream" % cx.args.backend}
+    if xb_cx <= 0 or xb_mhl <= 0:
+        raise SystemExit("selfcheck FAILED: the exchange step did not run (all-reduce bytes CX %d, lMHL %d over %d ranks): the "
+                         "check would not have covered the shared-tile path" % (xb_cx, xb_mhl, cx.world))
+    return {"rows_total": n_total, "cx_rows": nrow, "ok": True, "all_reduce_bytes": {"cx": int(xb_cx), "mhl": int(xb_mhl)},
+            "what": "sharded CX (thresholded) and lMHL tables, gathered on rank 0 over %s, bit-equal to the single-GPU tables of "
+                    "the same stream; %d cuts inside chromosomes, shared tiles all-reduced" % (cx.args.backend, cx.world - 1)}
 
 
 def streamed_and_d2h(cx, wl, res):
@@ -273,6 +311,122 @@ def streamed_and_d2h(cx, wl, res):
              "what": "pinned host SoA -> hipMemcpyAsync -> HBM -> one report (upload + report, best of 2 after a warm-up)"},
             {"ms": round(min(d2h) * 1e3, 3), "bytes": int(table_bytes), "GBps": round(table_bytes / min(d2h) / 1e9, 2),
              "what": "the report table (6 int32 columns) copied to pinned host memory"})
+
+
+def sharded_one_rank(cx, wl, res, steps):
+    """N=1: what the sharded driver costs per step on top of the plain call -- the same workload through HipShardEngine
+    with 14 forced shared tiles (two per cut of an 8-GPU run) and a REAL all-reduce over a world-size-1 nccl (RCCL) group:
+    slab zeroing, tile table with slots, slab dump, the collective, the second (emit) half, both host synchronisations."""
+    import numpy as np
+    torch, D, dist = cx.torch, cx.D, cx.dist
+    bam = res["bam"]
+    made_group = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=cx.dev)
+        made_group = True
+    try:
+        eng = D.HipShardEngine(bam)
+        c = cx.ea.CONTEXT_TO_BASES["CG"]
+        ctx = cx.ea.CONTEXT_TO_BASES[wl["report_context"]]["ctx_meth"]
+        thr = (c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1) if wl["threshold"] else None
+        first, last = eng.key_range("cx", ctx)
+        mid = (first + last) // 2
+        keys = np.arange(mid, mid + 14, dtype=np.int64)     # 14 consecutive tiles inside one chromosome
+        owned = np.ones(14, dtype=np.int32)
+
+        def step():
+            if thr is not None:
+                slab = eng.cx_accumulate_fused(thr, ctx, keys, owned)
+            else:
+                slab = eng.cx_accumulate(None, ctx, keys, owned)
+            dist.all_reduce(slab, op=dist.ReduceOp.SUM)
+            return eng.cx_finish(ctx)
+
+        cols = step()
+        ref = res["rep"]
+        same = bool(all(torch.equal(cols[i], ref[k]) for i, k in enumerate(("rname", "strand", "pos", "context", "meth", "unmeth"))))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        slab_bytes = int(eng._slab.numel() * eng._slab.element_size())
+    finally:
+        if made_group:
+            dist.destroy_process_group()
+    if not same:
+        raise SystemExit("sharded_1rank: the table through the shared-tile path differs from the plain call's")
+    return {"ms_per_step": round(ms, 4), "plain_ms_per_step": round(res["ms_per_step"], 4),
+            "overhead_ms": round(ms - res["ms_per_step"], 4), "shared_tiles": 14, "all_reduce_bytes": slab_bytes,
+            "backend": "nccl (RCCL), world size 1", "table_equal_to_plain": True,
+            "what": "the same workload through the sharded driver on one rank: 14 forced shared tiles dumped to the slab, "
+                    "all_reduce(sum) of the slab, owners' emit, ordered columns"}
+
+
+def host_out(cx, wl, res, steps=5):
+    """N=1: what a host binding (the R shim) sees -- the report with the table in HOST memory.  `table`: the one-call entry
+    point (epi_batch_cytosine_report / epi_batch_cx_report: library-owned malloc'ed columns).  `into`: the two-step form the
+    shim uses (epi_batch_*_begin, then epi_batch_cx_fetch_host straight into caller-owned columns), with fresh destination
+    arrays per call (what R does: new vectors, page faults included) and with reused ones."""
+    import ctypes as C
+    import numpy as np
+    lib, torch, _lib = cx.lib, cx.torch, cx.ea._lib
+    bam = res["bam"]
+    b = bam.batch()
+    c = cx.ea.CONTEXT_TO_BASES["CG"]
+    ctx = _lib.enc(cx.ea.CONTEXT_TO_BASES[wl["report_context"]]["ctx_meth"])
+    thr = [_lib.enc(c[k]) for k in ("ctx_meth", "ctx_unmeth", "ooctx_meth", "ooctx_unmeth")]
+
+    def table():
+        t = _lib.CxTable()
+        if wl["threshold"]:
+            _lib.check(lib.epi_batch_cytosine_report(b, thr[0], thr[1], thr[2], thr[3], 2, 0.5, 0.1, ctx, None, C.byref(t)))
+        else:
+            _lib.check(lib.epi_batch_cx_report(b, None, ctx, C.byref(t)))
+        n = t.nrow
+        lib.epi_cx_table_free(C.byref(t))
+        return n
+
+    keep = {}
+
+    def into(fresh):
+        nrow = C.c_int64(0)
+        if wl["threshold"]:
+            _lib.check(lib.epi_batch_cytosine_report_begin(b, thr[0], thr[1], thr[2], thr[3], 2, 0.5, 0.1, ctx, None, C.byref(nrow)))
+        else:
+            _lib.check(lib.epi_batch_cx_report_begin(b, None, ctx, C.byref(nrow)))
+        n = nrow.value
+        if fresh or keep.get("n") != n:
+            keep["cols"] = [np.empty(n, np.int32) for _ in range(6)]
+            keep["n"] = n
+        arr = (C.c_void_p * 6)(*[a.ctypes.data for a in keep["cols"]])
+        _lib.check(lib.epi_batch_cx_fetch_host(b, arr, None))
+        return n
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n = fn()
+        return (time.perf_counter() - t0) / steps * 1e3, n
+
+    ms_table, n1 = timeit(table)
+    ms_fresh, n2 = timeit(lambda: into(True))
+    ms_reuse, n3 = timeit(lambda: into(False))
+    rep = res["rep"]
+    ok = n1 == n2 == n3 == rep.nrow and all(np.array_equal(keep["cols"][i], rep[k].cpu().numpy())
+                                            for i, k in enumerate(("rname", "strand", "pos", "context", "meth", "unmeth")))
+    if not ok:
+        raise SystemExit("host_out: the host table differs from the device table")
+    return {"ms_table": round(ms_table, 3), "ms_into_fresh": round(ms_fresh, 3), "ms_into_reused": round(ms_reuse, 3),
+            "rows": int(n1), "bytes": int(n1) * 24,
+            "what": "report with the table in host memory: library-owned table (one call) / caller-owned columns allocated per "
+                    "call / caller-owned columns reused; pageable destinations through the engine's pinned staging pipeline"}
 
 
 def file_workload(cx, args):
@@ -370,7 +524,8 @@ def main():
     n_total = res["n_total"]
 
     if args.check and world > 1 and rank == 0 and wl["kind"] == "cx":
-        whole = cx.synth.generate_device(n_total=n_total, read_len=L, device=cx.local)
+        # the whole stream on rank 0 alone, same generator arguments (n_chr_for(world): the genome of the sharded run)
+        whole = make_batch(type("Whole", (), dict(world=world, rank=0, local=cx.local, synth=cx.synth))(), wl, n_total, L, n_total)
         ref = cx.ea.generateCytosineReport(whole, threshold_reads=wl["threshold"], report_context=wl["report_context"], as_device=True)
         ok = all(bool(torch.equal(ref[k], rep[k])) for k in ref)
         print("CHECK sharded == single-GPU table: %s (%d rows)" % (ok, ref.nrow), flush=True)
@@ -387,8 +542,13 @@ def main():
         kname = "mhl_tiles" if wl["kind"] == "mhl" else "cx_tiles"
         rows_this_rank = nrow_local if not gathered else nrow_out // world   # rows rank 0's kernel emitted
         row_bytes = 36 if wl["kind"] == "mhl" else 24
-        # L (xm) + 8 (off) + 12 (rname,strand,start) + 4 (pass) per read, + 24/36 B per output row
-        alg_bytes = res["nbytes_local"] + rows * (8 + 12 + 4) + row_bytes * rows_this_rank
+        # L (xm) + 8 (off) + 12 (rname,strand,start) + 4 (pass) per read, + 24/36 B per output row.  The step
+        # is charged all of it (step_frac); the tile kernel only what IT writes per output row (its pool rows: key, meth,
+        # unmeth = 12 B for CX; key, coverage and three 64-bit sums = 32 B for lMHL) -- the table columns are written by
+        # the gather kernel, whose time is in kernel_ms_all.
+        in_bytes = res["nbytes_local"] + rows * (8 + 12 + 4)
+        step_bytes = in_bytes + row_bytes * rows_this_rank
+        alg_bytes = in_bytes + (32 if wl["kind"] == "mhl" else 12) * rows_this_rank
         kms = res["kernels"].get(kname, 0.0)
         achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         traffic, tsrc = None, None
@@ -412,20 +572,24 @@ def main():
             "higher_is_better": True, "scaling": "strong" if wl.get("strong") else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
+                       "stream": wl.get("stream", "uniform"), "n_chr": n_chr_for(world),
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
-                       "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (RCCL); output rows %s"
-                                    % ("gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
+                       "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
+                                    % ("RCCL" if args.backend == "nccl" else args.backend + ", a rehearsal without RCCL",
+                                       "gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kms, 4),
-                         "kernel_ms_all": res["kernels"],
-                         "step_frac": round(alg_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / 8000.0, 5)},
+                         "kernel_ms_all": res["kernels"], "step_algorithmic_bytes": int(step_bytes),
+                         "step_frac": round(step_bytes / (res["ms_per_step"] * 1e-3) / 1e9 / 8000.0, 5)},
             "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
             "all_reduce_bytes_per_step": int(res["exchange_bytes"]), "selfcheck": check,
         }
     extras = not args.no_extras and not args.rows and not args.read_len
     if world == 1 and extras and wl["kind"] == "cx" and L <= 1000 and out is not None:
         out["streamed"], out["d2h"] = streamed_and_d2h(cx, wl, res)
+        out["host_out"] = host_out(cx, wl, res)
+        out["sharded_1rank"] = sharded_one_rank(cx, wl, res, max(5, args.steps))
     if world == 1 and args.cpu_sample > 0 and out is not None:
         out["cpu_baseline"] = cpu_baseline(bam, wl, min(args.cpu_sample, rows), np)
     elif out is not None:
@@ -439,11 +603,13 @@ def main():
 
     if extras and args.workload == "cfg2":
         if world == 1:
-            u = timed_run(cx, WORKLOADS["cfg2u"], rows, L, max(3, args.steps // 2), 1)
-            if out is not None:
-                out["cfg2u"] = {"value": round(u["n_total"] * max(3, args.steps // 2) / u["dt"] / 1e6, 3), "unit": "Mreads/s",
-                                "ms_per_step": round(u["ms_per_step"], 4), "vs_cfg2": round(u["ms_per_step"] / res["ms_per_step"], 3),
-                                "kernel_ms_all": u["kernels"], "what": WORKLOADS["cfg2u"]["desc"]}
+            k2 = max(3, args.steps // 2)
+            for name in ("cfg2g", "cfg2u", "cfg2p"):     # the three effects apart: start distribution / ragged + gaps / a pile-up
+                u = timed_run(cx, WORKLOADS[name], rows, L, k2, 1)
+                if out is not None:
+                    out[name] = {"value": round(u["n_total"] * k2 / u["dt"] / 1e6, 3), "unit": "Mreads/s",
+                                 "ms_per_step": round(u["ms_per_step"], 4), "vs_cfg2": round(u["ms_per_step"] / res["ms_per_step"], 3),
+                                 "kernel_ms_all": u["kernels"], "what": WORKLOADS[name]["desc"]}
         w3 = WORKLOADS["cfg3"]
         r3 = (w3["rows"] + world - 1) // world
         s3 = timed_run(cx, w3, r3, w3["read_len"], args.strong_steps, 1)

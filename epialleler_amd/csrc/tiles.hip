@@ -272,9 +272,11 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
       EPI_HIP(hipMemsetAsync(b->d_slot_tile.p, 0xFF, (size_t)nshared * 4, s));
     }
     EPI_HIP(hipMemsetAsync(d_misc, 0, 4, s));
+    prof_begin("tile_index", s);
     hipLaunchKernelGGL((k_tile_pass<true, true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh,
                        b->tile_bsum[slot].as<uint32_t>(), b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared,
                        b->d_slot_tile.as<int32_t>(), d_misc, (int64_t)nt);
+    prof_end("tile_index", s);
     EPI_HIP(hipGetLastError());
     *hinted = true;
     *ntiles_out = (int32_t)nt;

@@ -69,9 +69,13 @@ def _hash3_t(seed, stream, idx):
     return _mix64_t(idx ^ _s64(s))
 
 
-def uniform_layout(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None, device="cpu"):
+def uniform_layout(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None, device="cpu", ragged=True,
+                   pileup=None):
     """(rname, start, length) of rows [row_first, row_first+n) of the stream whose starts are uniform on each
-    chromosome and then sorted (torch, any device).  Template lengths are uniform in [0.8, 1.2] x mean_len."""
+    chromosome and then sorted (torch, any device).  Template lengths are uniform in [0.8, 1.2] x mean_len, or exactly
+    mean_len with ragged=False (SURVEY 8d's literal config 2: uniform starts, L = 300).  pileup = (first global row,
+    rows): those rows all start where the first of them does -- an amplicon-like pile-up inside a WGS-like stream
+    (clipped to the chromosome of its first row; sortedness is kept, the rows behind them start further right)."""
     import torch
     n = n_total - row_first if n is None else n
     rpc = (n_total + n_chr - 1) // n_chr
@@ -84,25 +88,32 @@ def uniform_layout(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=
         x = torch.arange(a, b, dtype=torch.int64, device=device)
         raw = 1 + _lsr(_hash3_t(seed, 1, x), 1) % chr_len
         srt = torch.sort(raw).values
+        if pileup is not None and a <= int(pileup[0]) < b:
+            p0, p1 = int(pileup[0]) - a, min(int(pileup[0]) + int(pileup[1]), b) - a
+            srt[p0:p1] = srt[p0]
         lo, hi = max(a, row_first) - a, min(b, row_first + n) - a
         st.append(srt[lo:hi].to(torch.int32))
         rn.append(torch.full((hi - lo,), c + 1, dtype=torch.int32, device=device))
     x = torch.arange(row_first, row_first + n, dtype=torch.int64, device=device)
     lens = lo_len + _lsr(_hash3_t(seed, 6, x), 1) % (hi_len - lo_len + 1)
+    if not ragged:
+        lens = torch.full_like(lens, int(mean_len))
     cat = lambda parts, dt: torch.cat(parts) if parts else torch.empty(0, dtype=dt, device=device)
     return cat(rn, torch.int32), cat(st, torch.int32), lens
 
 
 def generate_device_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None,
-                            gap_every=4, gap_len=50, device=None):
-    """Rows [row_first, row_first+n) of the uniform-start stream, resident on `device` (bench workload cfg2u)."""
+                            gap_every=4, gap_len=50, device=None, ragged=True, pileup=None):
+    """Rows [row_first, row_first+n) of the uniform-start stream, resident on `device`.  bench: cfg2 / cfg3 / cfg4 / cfg5
+    with ragged=False, gap_every=0 (uniform-random starts then sort, fixed L); cfg2u with the defaults
+    (ragged lengths, a 0xFB gap between the mates of every fourth template)."""
     import torch
     lib = _lib.load()
     if device is None:
         device = torch.cuda.current_device()
     n = n_total - row_first if n is None else n
     dev = "cuda:%d" % device
-    rname, start, lens = uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, dev)
+    rname, start, lens = uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, dev, ragged, pileup)
     off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=off[1:])
     nbytes = int(off[-1].item()) if n else 0

@@ -83,12 +83,12 @@ def random_templates(rng, n, min_len=0, max_len=400, n_rname=3, span=5000, p_gar
     return {"xm": xm, "off": off, "rname": rname, "strand": strand, "start": start}
 
 
-def generate_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None, gap_every=4, gap_len=50):
+def generate_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None, gap_every=4, gap_len=50, ragged=True, pileup=None):
     """numpy mirror of epialleler_amd.synth.generate_device_uniform (layout by the same torch code on the CPU, bytes by
     the same hashes as epi_synth_fill_dev)."""
     from epialleler_amd import synth
     n = n_total - row_first if n is None else n
-    rname, start, lens = (t.numpy() for t in synth.uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, "cpu"))
+    rname, start, lens = (t.numpy() for t in synth.uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, "cpu", ragged, pileup))
     off = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=off[1:])
     nb = int(off[-1])

@@ -406,7 +406,7 @@ def test_uniform_synth_matches_numpy_mirror(ea):
     """The SURVEY-8d-conformant generator (uniform starts sorted, ragged lengths, gapped templates; bench cfg2u)."""
     from epialleler_amd import synth
     for kw in (dict(n_total=4000), dict(n_total=9000, n_chr=3, row_first=2500, n=5000, gap_every=2, gap_len=31),
-               dict(n_total=1500, mean_len=120, depth=9, gap_every=0)):
+               dict(n_total=1500, mean_len=120, depth=9, gap_every=0), dict(n_total=5000, n_chr=3, gap_every=0, ragged=False)):
         bam = synth.generate_device_uniform(**kw)
         ref = synth_np.generate_uniform(**kw)
         d = bam.dev
