@@ -126,6 +126,9 @@ _SIGS = {
     "epi_batch_tile_key_range_for": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "epi_batch_mhl_set_shared": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     "epi_batch_mhl_finish_shared": (C.c_int, [_VP, _VP, C.POINTER(_I64)]),
+    "epi_mhl_fused_tile_positions": (C.c_int, []),
+    "epi_batch_mhl_fused_ok": (C.c_int, [_VP, _CS, _VP, C.POINTER(_I32)]),
+    "epi_batch_mhl_set_shared_fused": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     "epi_synth_generate_dev": (C.c_int, [C.POINTER(SynthParams), _VP, _VP, _VP, _VP, _VP, _VP]),
     "epi_synth_fill_dev": (C.c_int, [C.c_uint64, _I64, _I64, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP, _VP]),
     "epi_prof_enable": (None, [C.c_int]),

@@ -110,6 +110,8 @@ struct epi_batch {
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
   uint32_t mhlf_slot = 0;                      // ... and its fused kernel (1024-position tiles)
+  bool mhlf_prefer_wide = false;               // most tiles of the last fused lMHL report needed the u64 sums: start with that variant
+  bool mhl_shared_fused = false;               // the lMHL slabs attached are in the fused kernel's layout (mhl_common.hpp)
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes
   uint32_t cx_last_ctx_of_plane = 0;
@@ -124,7 +126,7 @@ struct epi_batch {
   size_t pool_cap2 = 0;     // rows that fit pool_d/pool_e (lMHL doubles)
 
   // state of the last report (for fetch)
-  int last_kind = 0;        // 0 none, 1 cx, 2 mhl
+  int last_kind = 0;        // 0 none, 1 cx, 2 mhl; 3 / 4 / 5: first half of a sharded cx / two-kernel lMHL / fused lMHL report
   int64_t last_nrow = 0;
   int32_t last_ntiles = 0;
   int32_t tile_hint_T[4] = {0, 0, 0, 0};    // tile counts of this (immutable) batch by tile size, as found by earlier calls
@@ -186,6 +188,7 @@ struct Options {
   int mhl_multi = 0;         // EPIHIP_MHL_MULTI     wavefront-per-read pass 1
   int mhl_group_g = 0, mhl_group_c = 0;   // EPIHIP_MHL_GROUP="G,C"
   int mhl_sums = 0;          // EPIHIP_MHL_SUMS      32 / 64
+  int mhlf_shape = 0;        // EPIHIP_MHLF_SHAPE="G,C"  lane shape of the one-pass lMHL kernel, as G * 8 + C
   int pr_group = 0;          // EPIHIP_GROUP         lanes per read of the general per-read kernel
   int pr_rpg = 0;            // EPIHIP_PR_RPG
   int pr_wide = 1;           // EPIHIP_PR_WIDE=0

@@ -46,6 +46,10 @@ static void read_options() {
   o.mhl_multi = getenv("EPIHIP_MHL_MULTI") != nullptr;
   if (const char *e = getenv("EPIHIP_MHL_GROUP")) { int g = 0, c = 0; if (sscanf(e, "%d,%d", &g, &c) == 2) { o.mhl_group_g = g; o.mhl_group_c = c; } else o.mhl_group_g = -1; }
   geti("EPIHIP_MHL_SUMS", &o.mhl_sums);
+  if (const char *e = getenv("EPIHIP_MHLF_SHAPE")) {
+    int g = 0, c = 0;
+    if (sscanf(e, "%d,%d", &g, &c) == 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && c >= 2 && c <= 4) o.mhlf_shape = g * 8 + c;
+  }
   geti("EPIHIP_GROUP", &o.pr_group);
   geti("EPIHIP_PR_RPG", &o.pr_rpg);
   if (const char *e = getenv("EPIHIP_PR_WIDE")) o.pr_wide = atoi(e) != 0;

@@ -30,56 +30,18 @@
 // Lane exchanges inside groups of up to 16 lanes are DPP moves, not __shfl (ds_bpermute).
 #include "common.hpp"
 #include "tile_common.hpp"
+#include "mhl_common.hpp"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 namespace epi {
 
-constexpr int MHL_WG = 512;                       // threads per workgroup of the heavy-tile and slab kernels
-constexpr int MHL_WG_SHORT = 256;                 // k_mhl_tiles for reads of one k_mhl_rows block: five workgroups per CU,
-                                                  // 10.8 against 11.6 ms on config 4 (long reads, whose record walk is
-                                                  // latency-bound, keep 512: 9.4 against 12.4 ms on 10 kb reads)
-constexpr int MHL_T = kMhlTile;
-// One difference array: entry of tile position p (0..T, T = "after the tile") sits at p + p/8 -- the padding makes the
-// prefix-sum phase, where a lane walks 8 consecutive entries, free of LDS bank conflicts (stride 9 x 8 bytes per lane).
-constexpr int MHL_SLEN = (kMhlTile + 1) + ((kMhlTile + 1) >> 3) + 1;
-__host__ __device__ constexpr int mhl_pad(int p) { return p + (p >> 3); }
-constexpr int MHL_NSUM = 6 * MHL_SLEN;            // u64 per tile: difference arrays of sum S(M), sum h, sum S(h), two strands each
-constexpr int MHL_BLK_SHIFT = 11;                 // a block of the multi-block row kernel: 64 lanes x 32 bytes
-constexpr int MHL_REGIONS = 64, MHL_CUR_STRIDE = 32;   // record allocation cursors (u64 each, 256 B apart)
-#ifndef EPI_MHL_NU
-#define EPI_MHL_NU CX_NU
-#endif
-constexpr int MHL_NU = EPI_MHL_NU;                // dword loads a lane keeps in flight per row in the tile kernel
-#ifndef EPI_MHL_WPS
-#define EPI_MHL_WPS 6
-#endif
 
-__host__ __device__ __forceinline__ uint64_t nrS(uint64_t n) { return n < 2 ? n : (n * (n + 1) * (n + 2)) / 6; }   // :39-43
-// mhl_lookup[n] (:110-116) without the table; indices clamp at 65535 (the reference's table ends there)
-__device__ __forceinline__ uint64_t mhl_lut(uint32_t n, uint32_t H) {
-  if (n > 65535u) n = 65535u;
-  const uint32_t k = n < H ? n : H;
-  // below 1024 the product fits 32 bits (three 64-bit multiplies and a 64-bit division by 6 otherwise: ~40 VALU);
-  // decided per wavefront, so short-read batches never execute the wide form
-  if (__builtin_expect(__ballot(k >= 1024u) != 0ull, 0)) return nrS(k);
-  return k < 2u ? (uint64_t)k : (uint64_t)((k * (k + 1u) * (k + 2u)) / 6u);
-}
 
 struct MhlRec { uint32_t first, last, m; };       // bytes [first,last] of the row; m = members of the stretch, 0 = counted run
 
-struct Seg { uint32_t has; uint32_t cnt; };       // scan element: saw a cut? members since the last cut
-__device__ __forceinline__ Seg seg_combine(Seg left, Seg right) {   // state after `left` then `right`
-  Seg r;
-  r.has = left.has | right.has;
-  r.cnt = right.has ? right.cnt : left.cnt + right.cnt;
-  return r;
-}
 
-// nibble -> flags: 1 member (in context, methylated), 2 cut (in context, unmethylated), 4 skipped ('+'/'-'/filler, :187),
-// 8 / 16 out-of-context methylated / unmethylated (:176-177).  Built on the host from the context string.
-struct MhlLut { uint32_t lo0, lo1, hi0, hi1; };
 
 struct RowsArgs {
   const uint8_t *xm;
@@ -99,32 +61,7 @@ struct RowsArgs {
   uint32_t *max_h;                        // largest haplotype size among the kept reads (sizes the LDS sums of pass 2)
 };
 
-// Per-byte bit masks of the 16*C bytes a lane owns: u32 for C = 2, u64 for C = 3, 4.
-template <int C> struct MaskOf { using T = uint64_t; };
-template <> struct MaskOf<2> { using T = uint32_t; };
-template <class M> struct Chunk { M U, L, K, V; uint32_t oom, oou; };
 
-__device__ __forceinline__ int bm_popc(uint32_t x) { return __popc(x); }
-__device__ __forceinline__ int bm_popc(uint64_t x) { return __popcll(x); }
-__device__ __forceinline__ int bm_ctz(uint32_t x) { return __ffs(x) - 1; }                    // x != 0
-__device__ __forceinline__ int bm_ctz(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
-__device__ __forceinline__ int bm_msb(uint32_t x) { return 31 - __clz(x); }                   // x != 0
-__device__ __forceinline__ int bm_msb(uint64_t x) { return 63 - __clzll((long long)x); }
-template <class M> __device__ __forceinline__ M bm_below(int n) {                              // bits [0, n), 0 <= n <= width
-  return n >= (int)(8 * sizeof(M)) ? ~(M)0 : (((M)1 << n) - (M)1);
-}
-
-// bit `bit` of the four bytes of f as a nibble
-__device__ __forceinline__ uint32_t plane_nibble(uint32_t f, int bit) {
-  uint32_t t = (f >> bit) & 0x01010101u;
-  t |= t >> 7;
-  t |= t >> 14;
-  return t & 0xFu;
-}
-
-// The 16*C bytes at g0 (16-byte aligned) of the row [rs,re), loaded (so that a caller can have the next chunk's loads
-// in flight while it works on this one) ...
-template <int C> struct ChunkRaw { uint32_t ww[4 * C]; int lo, hi; };       // hi <= lo: nothing of the row in this chunk
 
 template <int C>
 __device__ __forceinline__ ChunkRaw<C> mhl_chunk_load(const uint8_t *__restrict__ xm, int64_t g0, bool live, int64_t rs, int64_t re) {
@@ -212,12 +149,7 @@ __device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhl_chunk(const uint8_t 
   return mhl_chunk_masks<C>(mhl_chunk_load<C>(xm, g0, live, rs, re), lut);
 }
 
-template <class M> __device__ __forceinline__ uint32_t lead_members(const Chunk<M> &c) {    // members before the first cut (all if none)
-  return (uint32_t)bm_popc(c.U & (c.L ? ((c.L & ((M)0 - c.L)) - (M)1) : ~(M)0));
-}
-template <class M> __device__ __forceinline__ uint32_t trail_members(const Chunk<M> &c) {   // members after the last cut (all if none)
-  return (uint32_t)bm_popc(c.U & (c.L ? ~bm_below<M>(bm_msb(c.L) + 1) : ~(M)0));
-}
+
 
 // Span bytes of the chunk: bytes that have a member of their stretch at or before them AND at or after them
 // (segmented fills of the member bits, stopped by cuts; `enter` / `cont` = members of the open segment in the lanes
@@ -270,61 +202,7 @@ __device__ __forceinline__ bool mhl_keep(uint32_t h, uint32_t oo_m, uint32_t oo_
   return !((int)h < hmin || frac > max_oo);                                // :179
 }
 
-// Lane exchanges inside a group of G lanes as DPP moves where the distance allows (inside a row of 16 lanes): a
-// __shfl_* is a ds_bpermute through the LDS pipe with ~100 cycles of latency, and pass 1 chains about 35 of them per
-// wavefront.  A lane whose partner lies outside its group gets another group's value (or 0): callers mask those lanes.
-template <int CTRL>
-__device__ __forceinline__ uint32_t lane_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }   // (no source: 0)
-// (row shifts do not cross the rows of 16 lanes: groups of 32 or 64 lanes keep the shuffles)
-template <int G, int D>
-__device__ __forceinline__ uint32_t grp_up(uint32_t v) {             // value of lane - D
-  if constexpr (G > 16) return __shfl_up(v, D, 64);
-  else if constexpr (D == 1) return lane_dpp<0x111>(v);
-  else if constexpr (D == 2) return lane_dpp<0x112>(v);
-  else if constexpr (D == 4) return lane_dpp<0x114>(v);
-  else return lane_dpp<0x118>(v);
-}
-template <int G, int D>
-__device__ __forceinline__ uint32_t grp_down(uint32_t v) {           // value of lane + D
-  if constexpr (G > 16) return __shfl_down(v, D, 64);
-  else if constexpr (D == 1) return lane_dpp<0x101>(v);
-  else if constexpr (D == 2) return lane_dpp<0x102>(v);
-  else if constexpr (D == 4) return lane_dpp<0x104>(v);
-  else return lane_dpp<0x108>(v);
-}
-// partner for a butterfly reduction over a group, applied for D = G/2 ... 1: quad_perm for 1 and 2, row_half_mirror
-// (i <-> 7-i) for 4 and row_mirror (i <-> 15-i) for 8 pair up the same partial sums as lane ^ D would
-template <int D>
-__device__ __forceinline__ uint32_t grp_bfly(uint32_t v) {
-  if constexpr (D == 1) return lane_dpp<0xB1>(v);
-  else if constexpr (D == 2) return lane_dpp<0x4E>(v);
-  else if constexpr (D == 4) return lane_dpp<0x141>(v);
-  else if constexpr (D == 8) return lane_dpp<0x140>(v);
-  else return __shfl_xor(v, D, 64);
-}
 
-// segmented scans over the G lanes of a read: members of the open segment to the left (pf) / right (sf) of a lane
-template <int G, int D>
-__device__ __forceinline__ void seg_scan_steps(Seg &pf, Seg &sf, int sub) {
-  if constexpr (D < G) {
-    Seg l, r;
-    l.has = grp_up<G, D>(pf.has); l.cnt = grp_up<G, D>(pf.cnt);
-    if (sub >= D) pf = seg_combine(l, pf);
-    r.has = grp_down<G, D>(sf.has); r.cnt = grp_down<G, D>(sf.cnt);
-    if (sub + D < G) sf = seg_combine(r, sf);            // walking leftwards: `r` was seen first
-    seg_scan_steps<G, D * 2>(pf, sf, sub);
-  }
-}
-template <int D>
-__device__ __forceinline__ uint32_t grp_sum(uint32_t v) {            // over the 2*D lanes of a group, every lane gets it
-  if constexpr (D >= 1) { v += grp_bfly<D>(v); return grp_sum<D / 2>(v); }
-  else return v;
-}
-template <int D>
-__device__ __forceinline__ uint32_t grp_or(uint32_t v) {
-  if constexpr (D >= 1) { v |= grp_bfly<D>(v); return grp_or<D / 2>(v); }
-  else return v;
-}
 
 // Reads that fit one block of G lanes x 16*C bytes (every read of a short-read batch): 256/G reads per workgroup.
 template <int G, int C>
@@ -716,25 +594,6 @@ __device__ __forceinline__ void mhl_accumulate(const MhlArgs &a, const Tile &td,
 // carry the three integer sums; the two divisions (:92-93) are done by k_mhl_gather, one row per lane.
 // inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1, 2, 4, 8 inside a row of 16 lanes, then
 // row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): no LDS traffic, unlike __shfl_up (ds_bpermute)
-template <int CTRL, int ROWS>
-__device__ __forceinline__ uint32_t mhl_dpp(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, ROWS == 0xF);   // lanes without a source get 0
-}
-template <int CTRL, int ROWS>
-__device__ __forceinline__ unsigned long long mhl_dpp(unsigned long long v) {
-  return ((unsigned long long)mhl_dpp<CTRL, ROWS>((uint32_t)(v >> 32)) << 32) | mhl_dpp<CTRL, ROWS>((uint32_t)v);
-}
-template <class ST>
-__device__ __forceinline__ ST mhl_wave_scan(ST v) {
-  v += mhl_dpp<0x111, 0xF>(v);
-  v += mhl_dpp<0x112, 0xF>(v);
-  v += mhl_dpp<0x114, 0xF>(v);
-  v += mhl_dpp<0x118, 0xF>(v);
-  v += mhl_dpp<0x142, 0xA>(v);
-  v += mhl_dpp<0x143, 0xC>(v);
-  return v;
-}
-
 template <int WG, bool PK, class ST>
 __device__ __forceinline__ void mhl_emit(const MhlArgs &a, int tile, const MhlLds<ST> &L, uint32_t *s_scan) {
   constexpr int T = MHL_T;
@@ -995,414 +854,9 @@ __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ til
   }
 }
 
-// ---- fused kernel: pass 1 and pass 2 in ONE pass over the bytes -----------------------------------------------------------
-// For batches of short reads and a single haplotype context (generateMhlReport's default, ctx = "Zz") the tile
-// workgroup itself does the run-length analysis of every candidate row from the registers it has loaded (the body of
-// k_mhl_rows: bit planes, segmented lane scans, bit-parallel spans) and adds the results straight into LDS:
-//   * coverage as a difference array (+1 / -1 at the ends of the row; both strands packed in one dword; skipped and
-//     doubled codes corrected per byte),
-//   * n = calls of the context (either case) as u8 counters, four positions per dword: loads are position-aligned
-//     (16-byte chunks at any byte alignment), so a dword of xm is ONE ds_add_u32 instead of four,
-//   * the three sums (h, S(h), S(M)) as difference arrays, one interval per row / counted run / stretch piece.
-// Nothing is written to HBM between the two passes (no per-read info, no records) and xm is read once (rows that
-// reach into two tiles are analysed by both; the second visit is an L2 hit).  A row is emitted iff n > cov/2 (then no
-// other context can win the rule, :76-86).  Tiles with more than 255 candidate rows (u8 counters) or tiles shared
-// with other ranks make the caller fall back to the two-kernel path above.
-constexpr int MHLF_T = 1024, MHLF_WG = 512;
+size_t mhl_pool_rows(const epi_batch *b) { return b->pool_cap < b->pool_cap2 ? b->pool_cap : b->pool_cap2; }
 
-// mhl_keep's out-of-context test without the fp64 division per row (17 double-precision instructions per wavefront
-// step): (double)m / (double)n > max_oo is monotone in m, so per n there is a count of passing m = 0 .. n; the table is
-// filled on the device with the reference's own expression (:178-179; 0/0 = NaN compares false: kept).
-__global__ __launch_bounds__(256) void k_mhl_keep_table(double max_oo, int32_t nmax, uint32_t *__restrict__ tab) {
-  const int32_t n = (int32_t)(blockIdx.x * 256 + threadIdx.x);
-  if (n > nmax) return;
-  int32_t lo = 0, hi = n + 1;                              // first m in [0, n] with frac > max_oo (n + 1: none)
-  while (lo < hi) {
-    const int32_t m = (lo + hi) >> 1;
-    const double frac = (double)(uint32_t)m / (double)(uint64_t)(uint32_t)n;
-    if (frac > max_oo) hi = m; else lo = m + 1;
-  }
-  tab[n] = (uint32_t)lo;
-}
-
-struct MhlFArgs {
-  const uint8_t *xm;
-  const int64_t *off;
-  const int32_t *start, *strand;
-  int64_t xm_cap;                         // readable bytes behind xm
-  const Tile *tiles;
-  MhlLut lut;                             // flags: 1 member, 2 cut, 4 skipped, 8 / 16 out-of-context (un)methylated,
-                                          // 32 doubled (nibble 9), 64 / 128 / 192 stray nibble 3 / 4 / 8 (their counter IS a sum, :190)
-  int32_t hmin;
-  double max_oo;
-  const uint32_t *keep_tab;               // [n] = passing out-of-context methylated counts for n out-of-context calls (k_mhl_keep_table)
-  uint32_t H, ctx;                        // haplotype window clamp (:112), reported context code
-  uint32_t *pool_key, *pool_cov;
-  unsigned long long *pool_hs, *pool_nu, *pool_de;
-  uint32_t pool_cap, slot_rows, ovf_base;
-  uint32_t *cursor, *tile_nrow, *tile_base;
-  uint32_t *deep;                         // tiles with too many candidate rows for this kernel (the caller falls back)
-  int max_rows;
-  uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
-  int64_t nrows;
-};
-
-struct __attribute__((packed, aligned(1))) MhlU4u { uint32_t x, y, z, w; };
-
-// the W = 16*C bytes at byte offset g0 (any alignment, may reach outside [0, cap) for the first / last rows)
-template <int C>
-__device__ __forceinline__ ChunkRaw<C> mhlf_chunk_load(const uint8_t *__restrict__ xm, int64_t cap, int64_t g0, int64_t rs, int64_t re) {
-  constexpr int W = 16 * C;
-  ChunkRaw<C> r;
-  r.lo = 0; r.hi = 0;
-#pragma unroll
-  for (int j = 0; j < 4 * C; j++) r.ww[j] = 0u;
-  int64_t lo = rs - g0, hi = re - g0;
-  if (lo < 0) lo = 0;
-  if (hi > W) hi = W;
-  if (hi <= lo) return r;
-  r.lo = (int)lo; r.hi = (int)hi;
-  if (__builtin_expect(g0 < 0 || g0 + W > cap, 0)) {
-#pragma unroll
-    for (int j = 0; j < 4 * C; j++) {
-      uint32_t x = 0;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int64_t ad = g0 + 4 * j + q;
-        if (ad >= 0 && ad < cap) x |= (uint32_t)xm[ad] << (8 * q);
-      }
-      r.ww[j] = x;
-    }
-    return r;
-  }
-#pragma unroll
-  for (int j = 0; j < C; j++) {
-    if (j == 0 || g0 + 16 * j < re) {                      // (g0 >= 0 and g0 + W <= cap here: the edge path took the rest)
-      const MhlU4u w = *reinterpret_cast<const MhlU4u *>(xm + g0 + 16 * j);
-      r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
-    }
-  }
-  return r;
-}
-
-// Bit planes of a lane's W bytes for the fused kernel.  The LUT flags of bytes outside the row are NOT cleared dword by
-// dword (two of the eight lanes of a row hold an edge, so the masking code ran in every wavefront step): the planes
-// are ANDed with the valid-byte mask V instead, and the out-of-context counts are popcounts of masked planes.  f8 keeps
-// the raw flags (rare skip / double / stray bytes: their handler checks V itself).
-template <int C>
-__device__ __forceinline__ Chunk<typename MaskOf<C>::T> mhlf_chunk_masks(const ChunkRaw<C> &r, const MhlLut &lut, uint32_t (&f8)[4 * C]) {
-  using M = typename MaskOf<C>::T;
-  Chunk<M> c = {0, 0, 0, 0, 0u, 0u};
-#pragma unroll
-  for (int d = 0; d < 4 * C; d++) f8[d] = 0u;
-  if (r.hi <= r.lo) return c;
-  c.V = bm_below<M>(r.hi) & ~bm_below<M>(r.lo);
-  uint32_t kacc = 0;
-  uint32_t ulo = 0, uhi = 0, llo = 0, lhi = 0, mlo = 0, mhi = 0, nlo = 0, nhi = 0;   // mask bits 0-31 / 32-63 of U, L, oo meth, oo unmeth
-#pragma unroll
-  for (int e = 0; e < 2 * C; e++) {
-    uint32_t f[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int d = 2 * e + h;
-      const uint32_t lo3 = r.ww[d] & 0x07070707u;
-      const uint32_t pick = ((r.ww[d] >> 1) & 0x04040404u) | 0x03020100u;
-      f[h] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(lut.hi1, lut.hi0, lo3), __builtin_amdgcn_perm(lut.lo1, lut.lo0, lo3), pick);
-      f8[d] = f[h];
-      kacc |= f[h];
-    }
-    // flag bit b of eight bytes -> eight mask bits, scaled by 2^b: v_dot4_u32_u8 with weights 1..8 / 16..128
-    auto plane = [&](uint32_t bit) {
-      return __builtin_amdgcn_udot4(f[1] & (0x01010101u * bit), 0x80402010u,
-                                    __builtin_amdgcn_udot4(f[0] & (0x01010101u * bit), 0x08040201u, 0u, false), false);
-    };
-    const uint32_t ub = plane(1u), lb = plane(2u) >> 1, mb = plane(8u) >> 3, nb = plane(16u) >> 4;
-    const int sh = 8 * (e & 3);
-    if (e < 4) { ulo |= ub << sh; llo |= lb << sh; mlo |= mb << sh; nlo |= nb << sh; }
-    else { uhi |= ub << sh; lhi |= lb << sh; mhi |= mb << sh; nhi |= nb << sh; }
-  }
-  M om = (M)mlo, ou = (M)nlo;
-  c.U = (M)ulo; c.L = (M)llo;
-  if constexpr (sizeof(M) == 8) { c.U |= (M)uhi << 32; c.L |= (M)lhi << 32; om |= (M)mhi << 32; ou |= (M)nhi << 32; }
-  c.U &= c.V; c.L &= c.V;
-  c.oom = (uint32_t)bm_popc(om & c.V);
-  c.oou = (uint32_t)bm_popc(ou & c.V);
-  if (kacc & 0x04040404u) {                                   // skipped bytes are rare ('+'/'-', filler between mates)
-#pragma unroll
-    for (int d = 0; d < 4 * C; d++) c.K |= (M)plane_nibble(f8[d], 2) << (4 * d);
-    c.K &= c.V;
-  }
-  return c;
-}
-
-// span_bits with the two segmented fills done by carry propagation instead of log-step shifts: adding the member
-// bits to the mask of non-cut bytes lets a carry run upward through a segment until the next cut absorbs it; the
-// bits it flips (plus the members themselves) are the bytes at or above a member of their segment.  The downward fill
-// is the same on the bit-reversed words.
-__device__ __forceinline__ uint64_t mhlf_fill_up(uint64_t x, uint64_t m) {       // m: propagatable bits, x subset of m
-  return ((((x + m) ^ m) & m) | x);
-}
-template <int W, class M>
-__device__ __forceinline__ M mhlf_span_bits(const Chunk<M> &c, uint32_t enter, uint32_t cont) {
-  const uint64_t nl = (uint64_t)(~c.L & bm_below<M>(W));                       // non-cut bytes of the lane
-  const uint64_t x = (uint64_t)c.U | ((enter > 0u && !(c.L & (M)1)) ? 1ull : 0ull);
-  const uint64_t y = (uint64_t)c.U | ((cont > 0u && !((c.L >> (W - 1)) & (M)1)) ? (1ull << (W - 1)) : 0ull);
-  const uint64_t up = mhlf_fill_up(x, nl);
-  const uint64_t dn = __brevll(mhlf_fill_up(__brevll(y), __brevll(nl)));
-  return (M)(up & dn & nl) & ~c.K & c.V;
-}
-
-// calls fn(first bit, length, m) for every run of set bits (m as write_runs computes it).  The run and -- for stretches --
-// the segment between the surrounding cuts come from carry propagation (adding the lowest set bit to a mask flips the
-// bits above it up to the first gap) instead of count-zeros / shift / compare chains.
-template <int W, class M, class FN>
-__device__ __forceinline__ void mhlf_for_runs(M bits_, bool stretch, const Chunk<M> &c, uint32_t enter, uint32_t cont, FN fn) {
-  uint64_t bits = (uint64_t)bits_;
-  const uint64_t nl = (uint64_t)(~c.L & bm_below<M>(W)), rnl = __brevll(nl);  // non-cut bytes (and bit-reversed)
-  while (bits) {
-    const uint64_t low = bits & (0ull - bits);
-    const uint64_t run = ((bits + low) ^ bits) & bits;                           // the maximal run starting at `low`
-    const int f = bm_ctz(low), e = __popcll(run);
-    uint32_t m = 0;
-    if (stretch) {
-      // the run lies inside one segment (span bytes are never cuts): fill from its lowest bit up and down to the cuts
-      const uint64_t up = mhlf_fill_up(low, nl);
-      const uint64_t dn = __brevll(mhlf_fill_up(__brevll(low), rnl));
-      const uint64_t seg = up | dn;
-      m = ((seg & 1ull) ? enter : 0u) + (uint32_t)__popcll((uint64_t)c.U & seg) + (((seg >> (W - 1)) & 1ull) ? cont : 0u);
-    }
-    fn(f, e, m);
-    bits ^= run;
-  }
-}
-
-// +v on tile positions [a, b) of one (unpadded) difference array of MHLF_T entries
-template <class ST>
-__device__ __forceinline__ void mhlf_interval(ST *d, int a, int b, unsigned long long v) {
-  if (a < 0) a = 0;
-  if (a < b && a < MHLF_T) {
-    atomicAdd(d + a, (ST)v);
-    if (b < MHLF_T) atomicAdd(d + b, (ST)0 - (ST)v);
-  }
-}
-
-template <class ST> constexpr int mhlf_waves_per_simd() { return sizeof(ST) == 4 ? 8 : 4; }   // 38 / 62 KiB of LDS per workgroup
-
-template <int G, int C, class ST>
-__global__ __launch_bounds__(MHLF_WG, (mhlf_waves_per_simd<ST>())) void k_mhl_fused(MhlFArgs a, int ntiles) {
-  using M = typename MaskOf<C>::T;
-  constexpr int W = 16 * C, T = MHLF_T, Q = T / 4, R = 64 / G, NW = MHLF_WG / 64;
-  __shared__ __attribute__((aligned(16))) uint32_t s_n8[2 * Q];        // [strand][Q]: calls of the context, u8 x 4 positions
-  __shared__ __attribute__((aligned(16))) uint32_t s_cov[T];           // coverage difference array, '+' low half, '-' high half
-  __shared__ __attribute__((aligned(16))) ST s_sum[6 * T];             // [sum: S(M), h, S(h)][strand][T] difference arrays
-  __shared__ uint32_t s_scan[NW + 2];
-  __shared__ ST s_tot[6][NW];
-  __shared__ uint32_t s_ctot[NW];
-  const int chunk = (ntiles + 7) >> 3;                   // XCD-aware tile order, as the CX kernel
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= ntiles) return;
-  const Tile td = a.tiles[tile];
-  {
-    uint4 *z = reinterpret_cast<uint4 *>(s_n8);
-    for (int i = threadIdx.x; i < 2 * Q / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
-    z = reinterpret_cast<uint4 *>(s_cov);
-    for (int i = threadIdx.x; i < T / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
-    z = reinterpret_cast<uint4 *>(s_sum);
-    for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
-  }
-  if (td.row_hi - td.row_lo > a.max_rows || td.slot >= 0) {
-    if (threadIdx.x == 0) { atomicAdd(a.deep, 1u); a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
-    return;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & (G - 1), grp = lane / G;
-
-  // ---- accumulate: G lanes own a row, W contiguous bytes per lane; the next step's row columns are fetched early ----
-  int64_t n_rs = 0, n_re = 0;
-  int32_t n_st = 0, n_sd = 1;
-  {
-    const int r0 = td.row_lo + wave * R + grp;
-    if (r0 < td.row_hi) { n_rs = a.off[r0]; n_re = a.off[r0 + 1]; n_st = a.start[r0]; n_sd = a.strand[r0]; }
-  }
-  for (int rbase = td.row_lo + wave * R; rbase < td.row_hi; rbase += NW * R) {
-    const int r = rbase + grp;
-    const bool valid = r < td.row_hi;
-    if (!EPI_DEV_CHECK(a.dbg, !valid || (r >= 0 && r < a.nrows && n_re >= n_rs && n_re - n_rs <= (int64_t)G * W), 31, r, n_re - n_rs)) return;
-    const int64_t rs = n_rs, re = n_re;
-    const int32_t st = n_st, sd = n_sd;
-    const int32_t rel = (int32_t)((uint32_t)st - (uint32_t)td.pos0);       // tile position of the row's byte 0
-    const int32_t len = (int32_t)(re - rs);
-    const int32_t P0 = rel - (rel & 15) + sub * W;                          // tile position of this lane's byte 0 (multiple of 16)
-    const int64_t g0 = rs - (rel & 15) + (int64_t)sub * W;                  // its byte offset in xm
-    uint32_t f8[4 * C];
-    const ChunkRaw<C> raw = valid ? mhlf_chunk_load<C>(a.xm, a.xm_cap, g0, rs, re) : ChunkRaw<C>{{0}, 0, 0};
-    {
-      const int rn = r + NW * R;                                            // (in flight with the bytes)
-      n_rs = 0; n_re = 0; n_st = 0; n_sd = 1;
-      if (rn < td.row_hi) { n_rs = a.off[rn]; n_re = a.off[rn + 1]; n_st = a.start[rn]; n_sd = a.strand[rn]; }
-    }
-    const Chunk<M> c = mhlf_chunk_masks<C>(raw, a.lut, f8);
-
-    // members of the open segment to the left (enter) and to the right (cont) of this lane
-    Seg pf = {c.L ? 1u : 0u, trail_members(c)}, sf = {c.L ? 1u : 0u, lead_members(c)};
-    seg_scan_steps<G, 1>(pf, sf, sub);
-    uint32_t enter = grp_up<G, 1>(pf.cnt), cont = grp_down<G, 1>(sf.cnt);
-    if (sub == 0) enter = 0u;
-    if (sub == G - 1) cont = 0u;
-    const uint32_t h = grp_sum<G / 2>((uint32_t)bm_popc(c.U | c.L)), oo_m = grp_sum<G / 2>(c.oom), oo_u = grp_sum<G / 2>(c.oou);
-    const uint32_t anyk = grp_or<G / 2>(c.K ? 1u : 0u);
-    const bool keep = valid && len > 0 && !((int)h < a.hmin) && oo_m < a.keep_tab[oo_m + oo_u];   // :176-179 (mhl_keep)
-    if (keep) {
-      const int sidx = sd - 1;
-      const unsigned long long sh = mhl_lut(h, a.H);                         // S(h), :194
-      ST *dn = s_sum + (0 + sidx) * T, *dh = s_sum + (2 + sidx) * T, *dd = s_sum + (4 + sidx) * T;
-      const uint32_t unit = sidx ? 65536u : 1u;
-      if (sub == 0) {
-        mhlf_interval(s_cov, rel, rel + len, unit);                          // coverage of the whole row; skipped bytes corrected below
-        if (!anyk) {                                                         // every byte counted: one interval per sum (:192, :194)
-          mhlf_interval(dh, rel, rel + len, (unsigned long long)h);
-          mhlf_interval(dd, rel, rel + len, sh);
-        }
-      }
-      // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
-      const M P = mhlf_span_bits<W>(c, enter, cont);
-      mhlf_for_runs<W>(P, true, c, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(dn, P0 + f, P0 + f + e, mhl_lut(m, a.H)); });
-      if (anyk) {                                                            // reads with skipped bytes: h and S(h) per counted run
-        const M Qr = c.V & ~c.K;
-        mhlf_for_runs<W>(Qr, false, c, enter, cont, [&](int f, int e, uint32_t) {
-          mhlf_interval(dh, P0 + f, P0 + f + e, (unsigned long long)h);
-          mhlf_interval(dd, P0 + f, P0 + f + e, sh);
-        });
-      }
-      // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any (a nibble of the in-context
-      // plane is spread to four bytes by one multiplication)
-      uint32_t *n8 = s_n8 + sidx * Q + (P0 >> 2);
-      const uint64_t N = (uint64_t)(c.U | c.L);
-      uint32_t fl = 0;
-#pragma unroll
-      for (int e = 0; e < 2 * C; e++) {                                      // eight positions (two dwords of xm) per ds_add_u64
-        const uint32_t by = (uint32_t)(N >> (8 * e)) & 255u;
-        const uint32_t lo = ((by & 15u) * 0x00204081u) & 0x01010101u, hi = ((by >> 4) * 0x00204081u) & 0x01010101u;
-        fl |= f8[2 * e] | f8[2 * e + 1];
-        if (by != 0u && (uint32_t)((P0 >> 2) + 2 * e) < (uint32_t)Q)        // (P0 is a multiple of 16: the pair is aligned, and in or out together)
-          atomicAdd(reinterpret_cast<unsigned long long *>(n8 + 2 * e), (unsigned long long)lo | ((unsigned long long)hi << 32));
-      }
-      // rare bytes: skipped (coverage -1 over their runs), nibble 9 (coverage +1), stray nibbles 3 / 4 / 8 (+1 on the sum
-      // their counter is).  Kept compact (bit planes + loops over set bits): unrolled per byte it was most of the kernel's
-      // code and spilled scalar registers in the hot path.
-      if (__builtin_expect(c.K != 0, 0))
-        mhlf_for_runs<W>(c.K, false, c, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(s_cov, P0 + f, P0 + f + e, (unsigned long long)(0u - unit)); });
-      if (__builtin_expect((fl & 0xE0E0E0E0u) != 0u, 0)) {
-        M dbl = 0, s_lo = 0, s_hi = 0;                                       // planes of flag bits 5 (doubled), 6, 7 (stray id)
-        for (int d = 0; d < 4 * C; d++) {
-          dbl |= (M)plane_nibble(f8[d], 5) << (4 * d);
-          s_lo |= (M)plane_nibble(f8[d], 6) << (4 * d);
-          s_hi |= (M)plane_nibble(f8[d], 7) << (4 * d);
-        }
-        dbl &= c.V; s_lo &= c.V; s_hi &= c.V;                                // (flags of bytes outside the row are not cleared)
-        for (M m = dbl; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(s_cov, p, p + 1, unit); }
-        for (M m = s_lo & ~s_hi; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dn, p, p + 1, 1ull); }     // nibble 3
-        for (M m = s_hi & ~s_lo; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dd, p, p + 1, 1ull); }     // nibble 4
-        for (M m = s_lo & s_hi; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dh, p, p + 1, 1ull); }      // nibble 8
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- emit: prefix sums of the seven difference arrays (two consecutive positions per thread), rule, ordered rows ----
-  const int p0 = 2 * (int)threadIdx.x;
-  uint32_t cv[2] = {s_cov[p0], s_cov[p0 + 1]};
-  cv[1] += cv[0];
-  ST sv[6][2];
-#pragma unroll
-  for (int k = 0; k < 6; k++) { sv[k][0] = s_sum[k * T + p0]; sv[k][1] = sv[k][0] + s_sum[k * T + p0 + 1]; }
-  const uint32_t cinc = wave_scan_u32(cv[1]);
-  ST sinc[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) sinc[k] = mhl_wave_scan<ST>(sv[k][1]);
-  if (lane == 63) {
-    s_ctot[wave] = cinc;
-#pragma unroll
-    for (int k = 0; k < 6; k++) s_tot[k][wave] = sinc[k];
-  }
-  __syncthreads();
-  uint32_t cbefore = cinc - cv[1];
-  ST sbefore[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) sbefore[k] = sinc[k] - sv[k][1];
-  for (int w = 0; w < wave; w++) {
-    cbefore += s_ctot[w];
-#pragma unroll
-    for (int k = 0; k < 6; k++) sbefore[k] += s_tot[k][w];
-  }
-  uint32_t key[4], ncall[4];
-  unsigned long long hs[4], nu[4], de[4];
-  bool ok[4];
-  int nr = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {                              // key order: position, then '+' before '-'
-    const int j = i >> 1, s = i & 1, p = p0 + j;
-    const uint32_t cvv = cv[j] + cbefore;
-    const uint32_t cov = s ? cvv >> 16 : cvv & 0xFFFFu;
-    const uint32_t n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
-    ok[i] = n > (cov >> 1);                                  // :76-86: the context wins the rule iff its calls exceed half the coverage
-    key[i] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | a.ctx;
-    ncall[i] = n;                                            // coverage column, :90
-    nu[i] = (unsigned long long)(sv[0 + s][j] + sbefore[0 + s]);
-    hs[i] = (unsigned long long)(sv[2 + s][j] + sbefore[2 + s]);
-    de[i] = (unsigned long long)(sv[4 + s][j] + sbefore[4 + s]);
-    nr += ok[i];
-  }
-  uint32_t inc = (uint32_t)nr, wtot = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const unsigned long long bi = __ballot(ok[i]);
-    inc += __builtin_amdgcn_mbcnt_hi((uint32_t)(bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bi, 0u));
-    wtot += (uint32_t)__popcll(bi);
-  }
-  if (lane == 0) s_scan[wave] = wtot;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
-    uint32_t base = 0;
-    bool fits = true;
-    if (acc) {
-      if (acc <= a.slot_rows) base = (uint32_t)tile * a.slot_rows;
-      else {
-        const uint32_t o = atomicAdd(a.cursor, acc);
-        fits = (uint64_t)a.ovf_base + o + acc <= a.pool_cap;
-        base = a.ovf_base + o;
-      }
-    }
-    s_scan[NW + 1] = base;
-    s_scan[NW] = fits ? acc : 0xFFFFFFFFu;
-    a.tile_nrow[tile] = acc;
-    a.tile_base[tile] = base;
-  }
-  __syncthreads();
-  const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
-  if (total != 0xFFFFFFFFu) {
-    uint32_t w = base + inc - (uint32_t)nr + s_scan[wave];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (ok[i]) {
-        if (!EPI_DEV_CHECK(a.dbg, w < a.pool_cap, 33, w, a.pool_cap)) continue;
-        a.pool_key[w] = key[i];
-        a.pool_cov[w] = ncall[i];
-        a.pool_hs[w] = hs[i];
-        a.pool_nu[w] = nu[i];
-        a.pool_de[w] = de[i];
-        w++;
-      }
-    }
-  }
-}
-
-static size_t mhl_pool_rows(const epi_batch *b) { return b->pool_cap < b->pool_cap2 ? b->pool_cap : b->pool_cap2; }
-
-static int ensure_mhl_pool(epi_batch *b, size_t rows) {
+int ensure_mhl_pool(epi_batch *b, size_t rows) {
   if (rows > b->pool_cap || !b->pool_key.p) {
     EPI_TRY(b->pool_key.ensure(rows * 4));
     EPI_TRY(b->pool_a.ensure(rows * 4));
@@ -1461,7 +915,7 @@ static int pick_mhl_tile_group(int32_t max_len) {
 // k_mhl_rows variant for the batch: G lanes per read x 16*C bytes per lane, the smallest G*16*C that holds the longest
 // read wherever it starts inside its first 16 bytes; 0 = the batch has longer reads than 64 lanes cover (or
 // EPIHIP_MHL_MULTI is set): k_mhl_rows_multi.  Returned as G*8 + C.
-static int pick_mhl_group(int32_t max_len) {
+int pick_mhl_group(int32_t max_len) {
   if (options().mhl_multi) return 0;
   if (options().mhl_group_g > 0) {                                         // EPIHIP_MHL_GROUP="G,C" for A/B runs; must cover the reads
     const int g = options().mhl_group_g, c = options().mhl_group_c;
@@ -1481,7 +935,7 @@ static int pick_mhl_group(int32_t max_len) {
 }
 
 // nibble -> MhlLut flags for one context set (rcpp_mhl_report.cpp:104-107, :176-177, :187)
-static MhlLut make_mhl_lut(uint32_t ctx_mask) {
+MhlLut make_mhl_lut(uint32_t ctx_mask) {
   uint32_t w[4] = {0, 0, 0, 0};
   for (uint32_t code = 0; code < 16; code++) {
     const bool in = (ctx_mask >> code) & 1u;
@@ -1495,148 +949,6 @@ static MhlLut make_mhl_lut(uint32_t ctx_mask) {
   MhlLut l;
   l.lo0 = w[0]; l.lo1 = w[1]; l.hi0 = w[2]; l.hi1 = w[3];
   return l;
-}
-
-// nibble -> flags of the fused kernel (MhlFArgs::lut)
-static MhlLut make_mhlf_lut(uint32_t ctx_mask) {
-  MhlLut l = make_mhl_lut(ctx_mask);
-  uint32_t *w[4] = {&l.lo0, &l.lo1, &l.hi0, &l.hi1};
-  auto add = [&](uint32_t code, uint32_t f) { *w[code >> 2] |= f << (8 * (code & 3)); };
-  add(9, 32u);                                             // counts twice in the coverage (its counter is the coverage slot, :191)
-  add(3, 64u); add(4, 128u); add(8, 192u);                 // their counters are the sums of :193, :194, :192
-  return l;
-}
-
-template <class ST>
-static void launch_mhl_fused(int gc, int nt, hipStream_t s, const MhlFArgs &a) {
-  const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
-#define EPI_LAUNCH(GG)                                                                                              \
-  case GG * 8 + 2: hipLaunchKernelGGL((k_mhl_fused<GG, 2, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 8 + 3: hipLaunchKernelGGL((k_mhl_fused<GG, 3, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 8 + 4: hipLaunchKernelGGL((k_mhl_fused<GG, 4, ST>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-  switch (gc) {
-    EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
-    default: break;
-  }
-#undef EPI_LAUNCH
-}
-
-// The fused path (k_mhl_fused).  *done = false: the batch is not eligible, or a tile turned out too deep -- the caller
-// runs the two-kernel path instead.
-static int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, double max_oo, hipStream_t s,
-                            int64_t *nrow_out, bool *done) {
-  *done = false;
-  const int enabled = options().mhl_fused;                 // test hook: EPIHIP_MHL_FUSED=0 keeps every batch on the two-kernel path
-  if (!enabled || !b->shared_keys.empty()) return EPI_OK;
-  uint32_t k = 0;
-  for (uint32_t c : {2u, 6u, 7u}) if (ctx_mask == ((1u << c) | (1u << (c + 8)))) k = c;
-  if (!k) return EPI_OK;                                   // one context, both cases (generateMhlReport's "Zz", "Xx", "Hh")
-  constexpr int T = MHLF_T;
-  RowStats st;
-  int32_t nt = 0;
-  bool nt_hinted = false;                                  // (a remembered tile count is verified at the synchronisation below)
-  EPI_TRY(build_tiles(b, s, T, &st, &nt, &nt_hinted));
-  const int gc = pick_mhl_group(st.max_len);
-  if (gc == 0 || options().mhl_group_g != 0) return EPI_OK;  // reads longer than one block of lanes: wavefront-per-read path
-  b->last_ntiles = nt;
-  if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; *done = true; return EPI_OK; }
-  // u32 LDS sums while 255 rows of the largest possible value stay below 2^31 (h <= read length)
-  uint32_t hcap = (uint32_t)st.max_len > 65535u ? 65535u : (uint32_t)st.max_len;
-  if (hcap >= H) hcap = H;
-  const unsigned long long vmax = nrS(hcap) > 1 ? nrS(hcap) : 1;
-  const bool narrow = ((1ull << 31) - 1) / (vmax + 2) >= 255;
-  EPI_TRY(b->tile_nrow.ensure((size_t)nt * 4));
-  EPI_TRY(b->tile_base.ensure((size_t)nt * 4));
-  EPI_TRY(b->tile_out.ensure((size_t)(nt + 1) * 4));
-  uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc layout as in the CX report: [1] cursor, [2] rows, [3] deep tiles
-  if (!b->mhlf_slot) b->mhlf_slot = T / 8;
-  uint32_t slot = b->mhlf_slot > 2u * T ? 2u * T : b->mhlf_slot;
-  if (options().mhl_slot >= 0 && options().mhl_slot <= 2 * T) slot = (uint32_t)options().mhl_slot;   // test hook (EPIHIP_MHL_SLOT)
-  while (slot && (unsigned long long)nt * slot > 0xC0000000ull) slot >>= 1;
-  size_t ovf_base = (size_t)nt * slot;
-  for (;;) {
-    const size_t ovf = (ovf_base >> 4) > 65536 ? (ovf_base >> 4) : 65536;
-    if (mhl_pool_rows(b) >= ovf_base + ovf) break;
-    const int rc = ensure_mhl_pool(b, ovf_base + ovf);
-    if (rc == EPI_OK) break;
-    b->pool_cap = 0; b->pool_cap2 = 0;
-    if (!slot) return rc;
-    slot = 0;
-    ovf_base = 0;
-  }
-  MhlFArgs a;
-  memset(&a, 0, sizeof(a));
-  a.xm = b->xm; a.off = b->off; a.start = b->start; a.strand = b->strand;
-  a.xm_cap = (b->nbytes + 15) / 16 * 16;
-  a.tiles = b->tiles.as<Tile>();
-  a.lut = make_mhlf_lut(ctx_mask);
-  a.hmin = (int32_t)hmin; a.max_oo = max_oo; a.H = H; a.ctx = k;
-  {                                                        // decision table over 0 .. longest row; kept while max_oo does not change
-    const bool same = b->mhl_keep_len == st.max_len && memcmp(&b->mhl_keep_oo, &max_oo, sizeof(double)) == 0;
-    if (!same) {
-      EPI_TRY(b->mhl_keep_tab.ensure((size_t)(st.max_len + 1) * 4));
-      hipLaunchKernelGGL(k_mhl_keep_table, dim3((unsigned)(st.max_len / 256 + 1)), dim3(256), 0, s, max_oo, st.max_len, b->mhl_keep_tab.as<uint32_t>());
-      EPI_HIP(hipGetLastError());
-      b->mhl_keep_len = st.max_len;
-      b->mhl_keep_oo = max_oo;
-    }
-    a.keep_tab = b->mhl_keep_tab.as<uint32_t>();
-  }
-  a.cursor = cursor;
-  a.tile_nrow = b->tile_nrow.as<uint32_t>();
-  a.tile_base = b->tile_base.as<uint32_t>();
-  a.deep = b->misc.as<uint32_t>() + 3;
-  a.max_rows = 255;
-  if (options().heavy_rows > 0 && options().heavy_rows < 255) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
-  a.slot_rows = slot;
-  a.ovf_base = (uint32_t)ovf_base;
-  EPI_TRY(check_grid(((int64_t)nt + 7) / 8 * 8, MHLF_WG, "lMHL tile kernel"));
-  a.nrows = b->n;
-#ifdef EPI_CHECK
-  EPI_TRY(b->diag.ensure(256));
-  a.dbg = b->diag.as<uint32_t>();
-  EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
-#endif
-  uint32_t host[3] = {0, 0, 0};
-  for (int attempt = 0; attempt < 2; attempt++) {
-    a.pool_key = b->pool_key.as<uint32_t>();
-    a.pool_cov = b->pool_a.as<uint32_t>();
-    a.pool_hs = b->pool_d.as<unsigned long long>();
-    a.pool_nu = b->pool_e.as<unsigned long long>();
-    a.pool_de = b->pool_f.as<unsigned long long>();
-    a.pool_cap = (uint32_t)(mhl_pool_rows(b) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : mhl_pool_rows(b));
-    if (attempt > 0) EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));
-    prof_begin("mhl_tiles", s);
-    if (narrow) launch_mhl_fused<uint32_t>(gc, nt, s, a); else launch_mhl_fused<unsigned long long>(gc, nt, s, a);
-    prof_end("mhl_tiles", s);
-    EPI_HIP(hipGetLastError());
-    EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    uint32_t host4[4];
-    EPI_TRY(read_scalars(b, s, cursor - 1, 16, host4));    // {tile count, overflow rows handed out, total rows, deep tiles}
-    if (nt_hinted && host4[0] != (uint32_t)nt) {
-      for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
-      return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host4[0], nt);
-    }
-    host[0] = host4[1]; host[1] = host4[2]; host[2] = host4[3];
-#ifdef EPI_CHECK
-    {
-      uint32_t d[8];
-      EPI_HIP(hipMemcpy(d, a.dbg, 32, hipMemcpyDeviceToHost));
-      if (d[0]) return fail(EPI_ERR_STATE, "fused lMHL index check %u failed: v0=%d v1=%d block=%u thread=%u (n=%lld nt=%d)", d[0],
-                            (int)d[1], (int)d[2], d[3], d[4], (long long)b->n, nt);
-    }
-#endif
-    if (host[2] > 0) return EPI_OK;                        // a tile with more rows than u8 counters take: two-kernel path
-    if (ovf_base + host[0] <= a.pool_cap) break;
-    if (attempt == 1) return fail(EPI_ERR_STATE, "row pool overflow after regrow");
-    EPI_TRY(ensure_mhl_pool(b, ovf_base + host[0] + (host[0] >> 4) + 1024));
-  }
-  if (host[0] > host[1] / 8 && b->mhlf_slot < 2u * T) b->mhlf_slot *= 2;
-  b->last_kind = 2;
-  b->last_nrow = host[1];
-  *nrow_out = host[1];
-  *done = true;
-  return EPI_OK;
 }
 
 }  // namespace epi
@@ -1876,15 +1188,38 @@ int epi_batch_mhl_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t 
   b->d_slab = nullptr;
   b->d_mhl_cnt_slab = nshared > 0 ? d_cnt_slab : nullptr;
   b->d_mhl_sum_slab = nshared > 0 ? d_sum_slab : nullptr;
+  b->mhl_shared_fused = false;
+  return EPI_OK;
+}
+
+int epi_mhl_fused_tile_positions(void) { return MHLF_T; }
+
+int epi_batch_mhl_fused_ok(epi_batch *b, const char *ctx, void *stream, int32_t *ok_out) {
+  if (!b || !ctx || !ok_out) return fail(EPI_ERR_ARG, "epi_batch_mhl_fused_ok: NULL argument");
+  *ok_out = 0;
+  EPI_HIP(hipSetDevice(b->eng->device));
+  uint32_t ctx_mask = 0;
+  for (const unsigned char *c = reinterpret_cast<const unsigned char *>(ctx); *c; c++) ctx_mask |= 1u << ctx_to_idx(*c);
+  if (b->n == 0) { RowStats st; memset(&st, 0, sizeof(st)); *ok_out = mhl_fused_eligible(b, ctx_mask, st) ? 1 : 0; return EPI_OK; }
+  EPI_TRY(fetch_row_stats(b, pick_stream(b, stream)));
+  *ok_out = (!b->h_stats.bad_len && mhl_fused_eligible(b, ctx_mask, b->h_stats)) ? 1 : 0;
+  return EPI_OK;
+}
+
+int epi_batch_mhl_set_shared_fused(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
+                                   int32_t *d_cnt_slab, int64_t *d_sum_slab) {
+  EPI_TRY(epi_batch_mhl_set_shared(b, h_keys, h_owned, nshared, d_cnt_slab, d_sum_slab));
+  b->mhl_shared_fused = nshared > 0;
   return EPI_OK;
 }
 
 // Second half of a sharded lMHL report: the slabs have been sum-reduced across ranks.
 int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out) {
   if (!b || !nrow_out) return fail(EPI_ERR_ARG, "epi_batch_mhl_finish_shared: NULL argument");
-  if (b->last_kind != 4) return fail(EPI_ERR_STATE, "epi_batch_mhl_finish_shared without a sharded epi_batch_mhl_report_dev");
+  if (b->last_kind != 4 && b->last_kind != 5) return fail(EPI_ERR_STATE, "epi_batch_mhl_finish_shared without a sharded epi_batch_mhl_report_dev");
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
+  if (b->last_kind == 5) return mhl_fused_finish_shared(b, s, nrow_out);   // the one-pass kernel's slabs
   const int32_t nt = b->last_ntiles;
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
   MhlArgs a;

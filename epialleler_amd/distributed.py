@@ -82,9 +82,19 @@ class HipShardEngine:
         """Positions per CX tile for this report context string (one reported context: 2048, else 1024)."""
         return self.lib.epi_cx_tile_positions(_lib.enc(ctx))
 
+    def mhl_fused_ok(self, ctx):
+        """Can THIS rank's rows take the one-pass lMHL kernel for `ctx`?  (All ranks must take the same path: the
+        answers are combined in _exchange_ranges.)"""
+        ok = C.c_int32(0)
+        _lib.check(self.lib.epi_batch_mhl_fused_ok(self.h, _lib.enc(ctx), _stream(self.bam.device), C.byref(ok)))
+        return bool(ok.value)
+
+    def mhl_tile_positions(self, fused):
+        return self.lib.epi_mhl_fused_tile_positions() if fused else self.lib.epi_mhl_tile_positions()
+
     def key_range(self, kind="cx", ctx="Z"):
         # a property of the resident (immutable) shard and the tile grid: computed once per tile size
-        T = self.tile_positions(ctx) if kind == "cx" else self.lib.epi_mhl_tile_positions()
+        T = self.tile_positions(ctx) if kind == "cx" else self.mhl_tile_positions(kind == "mhlf")
         if (kind, T) not in self._range:
             a, b = C.c_int64(0), C.c_int64(-1)
             _lib.check(self.lib.epi_batch_tile_key_range_for(self.h, T, _stream(self.bam.device), C.byref(a), C.byref(b)))
@@ -149,15 +159,25 @@ class HipShardEngine:
 
 
     # ---- lMHL -----------------------------------------------------------------------------------
-    def mhl_accumulate(self, ctx, hmax, hmin, max_oo, keys, owned):
+    def mhl_accumulate(self, ctx, hmax, hmin, max_oo, keys, owned, fused=False):
         torch = self.torch
-        T, NS = self.lib.epi_mhl_tile_positions(), self.lib.epi_mhl_slab_sums()
         n = max(keys.size, 1)
-        self._mcnt = torch.zeros(n * 16 * T, dtype=torch.int32, device=self.device)
-        self._msum = torch.zeros(n * NS, dtype=torch.int64, device=self.device)
+        if fused:        # the one-pass kernel's slabs: int32 [n][4][T] and int64 [n][6][T] (include/epihip.h)
+            T = self.lib.epi_mhl_fused_tile_positions()
+            want = (n * 4 * T, n * 6 * T)
+        else:
+            T, NS = self.lib.epi_mhl_tile_positions(), self.lib.epi_mhl_slab_sums()
+            want = (n * 16 * T, n * NS)
+        if getattr(self, "_mcnt", None) is None or (self._mcnt.numel(), self._msum.numel()) != want:
+            self._mcnt = torch.zeros(want[0], dtype=torch.int32, device=self.device)
+            self._msum = torch.zeros(want[1], dtype=torch.int64, device=self.device)
+        else:
+            self._mcnt.zero_()
+            self._msum.zero_()
         keys = np.ascontiguousarray(keys, np.int64)
         owned = np.ascontiguousarray(owned, np.int32)
-        _lib.check(self.lib.epi_batch_mhl_set_shared(
+        set_shared = self.lib.epi_batch_mhl_set_shared_fused if fused else self.lib.epi_batch_mhl_set_shared
+        _lib.check(set_shared(
             self.h, C.c_void_p(keys.ctypes.data) if keys.size else None,
             C.c_void_p(owned.ctypes.data) if keys.size else None, int(keys.size),
             C.c_void_p(self._mcnt.data_ptr()) if keys.size else None,
@@ -193,17 +213,31 @@ def _exchange_ranges(engine, kind, group, ctx="Z"):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     memo = engine.__dict__.setdefault("_all_ranges", {})
     T = engine.tile_positions(ctx) if kind == "cx" else 0
-    kind = (kind, T)
+    kind = (kind, T if kind == "cx" else ctx)
     if (kind, id(group), world) in memo:
         return memo[(kind, id(group), world)], world, rank
-    first, last = engine.key_range(kind[0]) if kind[0] != "cx" else engine.key_range("cx", ctx)
-    if world > 1:
-        mine = torch.tensor([first, last], dtype=torch.int64, device=engine.device)
-        allr = [torch.empty(2, dtype=torch.int64, device=engine.device) for _ in range(world)]
-        dist.all_gather(allr, mine, group=group)
-        ranges = [tuple(int(v) for v in t.cpu().tolist()) for t in allr]
+    if kind[0] == "cx":
+        first, last = engine.key_range("cx", ctx)
+        mine = [first, last]
     else:
-        ranges = [(first, last)]
+        # lMHL: both tile grids' ranges and whether this rank's rows allow the one-pass kernel; the ranks take it only
+        # if all of them can (one all_gather decides path and shared tiles alike)
+        ok = int(engine.mhl_fused_ok(ctx)) if hasattr(engine, "mhl_fused_ok") else 0
+        f2, l2 = engine.key_range("mhl")
+        f1, l1 = engine.key_range("mhlf") if ok else (0, -1)
+        mine = [f2, l2, f1, l1, ok]
+    if world > 1:
+        t_mine = torch.tensor(mine, dtype=torch.int64, device=engine.device)
+        allr = [torch.empty(len(mine), dtype=torch.int64, device=engine.device) for _ in range(world)]
+        dist.all_gather(allr, t_mine, group=group)
+        rows = [[int(v) for v in t.cpu().tolist()] for t in allr]
+    else:
+        rows = [mine]
+    if kind[0] == "cx":
+        ranges = [tuple(r) for r in rows]
+    else:
+        fused = all(r[4] for r in rows)
+        ranges = ([(r[2], r[3]) for r in rows] if fused else [(r[0], r[1]) for r in rows], fused)
     memo[(kind, id(group), world)] = ranges
     return ranges, world, rank
 
@@ -239,10 +273,13 @@ def sharded_mhl_report(engine, ctx, hmax, hmin, max_ooctx_meth_frac, group=None,
     """rcpp_mhl_report over row-range shards (same exchange as the CX table, on 512-position tiles; the
     64-bit sums travel as int64 and add with wrap-around, which is what unsigned addition does)."""
     import torch.distributed as dist
-    ranges, world, rank = _exchange_ranges(engine, "mhl", group)
+    (ranges, fused), world, rank = _exchange_ranges(engine, "mhl", group, ctx)
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
-    cnt_slab, sum_slab = engine.mhl_accumulate(ctx, hmax, hmin, max_ooctx_meth_frac, keys, owned)
+    if fused:
+        cnt_slab, sum_slab = engine.mhl_accumulate(ctx, hmax, hmin, max_ooctx_meth_frac, keys, owned, fused=True)
+    else:
+        cnt_slab, sum_slab = engine.mhl_accumulate(ctx, hmax, hmin, max_ooctx_meth_frac, keys, owned)
     engine.last_exchange_bytes = (int(cnt_slab.numel() * cnt_slab.element_size() + sum_slab.numel() * sum_slab.element_size())
                                   if (world > 1 and keys.size) else 0)
     if world > 1 and keys.size:

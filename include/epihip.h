@@ -289,6 +289,16 @@ int epi_batch_tile_key_range_for(epi_batch *b, int tile_positions, void *stream,
 int epi_batch_mhl_set_shared(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
                              int32_t *d_cnt_slab, int64_t *d_sum_slab);
 int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out);
+/* The one-pass lMHL kernel shards as well: tiles of epi_mhl_fused_tile_positions() positions, slabs int32
+ * [nshared][4][T] (calls of the context '+', '-'; coverage differences '+', '-') and int64 [nshared][6][T] (difference
+ * arrays of the three sums, two strands each).  Every rank must take the same path: epi_batch_mhl_fused_ok says whether
+ * THIS rank's rows allow the one-pass kernel for `ctx` (one haplotype context, reads of at most 4 KiB); the caller
+ * combines the answers (distributed.py: all ranks, once per shard) and attaches the slabs with the matching call.
+ * epi_batch_mhl_report_dev and epi_batch_mhl_finish_shared are then used as for the two-kernel layout. */
+int epi_mhl_fused_tile_positions(void);
+int epi_batch_mhl_fused_ok(epi_batch *b, const char *ctx, void *stream, int32_t *ok_out);
+int epi_batch_mhl_set_shared_fused(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
+                                   int32_t *d_cnt_slab, int64_t *d_sum_slab);
 
 /* ---- synthetic input (bench/tests; DESIGN.md "Synthetic workload") ------- */
 typedef struct {

@@ -127,6 +127,17 @@ def _rccl_worker(rank, port, outdir):
     mn = ("rname", "strand", "pos", "context", "coverage", "length", "lmhl")
     mc = [icols[i] for i in range(5)] + [dcols[i] for i in range(2)]
     np.savez(os.path.join(outdir, "rccl_mhl.npz"), **{k: v.cpu().numpy() for k, v in zip(mn, mc)})
+    # the same through the one-pass kernel's slab layout (1024-position tiles, int32 [4][T] + int64 [6][T] per tile)
+    assert eng.mhl_fused_ok("Zz")
+    ffirst, flast = eng.key_range("mhlf")
+    fkeys = np.array([k for k in range(ffirst, ffirst + 3) if (k >> 32) == (ffirst >> 32) and k <= flast], dtype=np.int64)
+    cnt_slab, sum_slab = eng.mhl_accumulate("Zz", 0, 0, 0.1, fkeys, np.ones(fkeys.size, dtype=np.int32), fused=True)
+    assert cnt_slab.numel() == fkeys.size * 4 * 1024 and sum_slab.numel() == fkeys.size * 6 * 1024 and int(cnt_slab.abs().sum()) > 0
+    dist.all_reduce(cnt_slab, op=dist.ReduceOp.SUM)
+    dist.all_reduce(sum_slab, op=dist.ReduceOp.SUM)
+    icols, dcols = eng.mhl_finish()
+    mc = [icols[i] for i in range(5)] + [dcols[i] for i in range(2)]
+    np.savez(os.path.join(outdir, "rccl_mhlf.npz"), **{k: v.cpu().numpy() for k, v in zip(mn, mc)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -141,6 +152,7 @@ def test_rccl_single_rank_slab_roundtrip(tmp_path):
     H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_cx.npz"))), want)
     want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", 0, 0, 0.1)
     H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_mhl.npz"))), want, float_cols=("length", "lmhl"))
+    H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_mhlf.npz"))), want, float_cols=("length", "lmhl"))
 
 
 def _nccl_worker(rank, world, port, outdir):
