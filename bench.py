@@ -217,7 +217,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False):
     cx.lib.epi_prof_enable(0)
     dt = cx.max_over_ranks(dt)
     kernels = {}
-    for nm in (b"threshold", b"cx_tiles", b"cx_heavy", b"mhl_rows", b"mhl_tiles", b"mhl_deep", b"mhl_heavy", b"tile_index", b"gather"):
+    for nm in (b"threshold", b"cx_tiles", b"cx_deep", b"cx_heavy", b"mhl_rows", b"mhl_tiles", b"mhl_deep", b"mhl_heavy", b"tile_index", b"gather"):
         m2, c2 = C.c_double(0), C.c_int64(0)
         cx.lib.epi_prof_get(nm, C.byref(m2), C.byref(c2))
         if c2.value:

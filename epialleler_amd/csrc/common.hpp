@@ -105,6 +105,7 @@ struct epi_batch {
   epi::DevBuf mhl_m, mhl_h, mhl_blk, mhl_cont, mhl_cur;   // lMHL pass 1: stretch records, per-read info, record table, block carries
   size_t mhl_rec_cap = 0;   // records that fit mhl_m
   epi::DevBuf heavy_list, heavy_slab, heavy_sums;   // ultra-deep tiles: ids and dense counters (+ lMHL sums)
+  epi::DevBuf deep_list;                            // CX report: tiles the lean kernel hands to the general one
   epi::DevBuf diag;                     // check / timing builds only
   size_t pool_cap = 0;      // rows that fit pool_key/pool_a/pool_b
   uint32_t cx_slot_cg = 0, cx_slot_wide = 0;   // pool rows per tile slot: CpG-only reports / reports with CHG, CHH (adapted per call)

@@ -94,9 +94,15 @@ struct Cx2Args {
   // ultra-deep tiles (amplicon pile-ups) are set aside by k_cx_tiles and split over many workgroups
   int heavy_rows;                         // a tile with more candidate rows than this is "heavy"
   int heavy_chunk;                        // rows per work item of k_cx_heavy
+  int heavy_first;                        // the heavy kernels work on heavy_list[heavy_first + blockIdx.y]; entries at or behind
+                                          // *heavy_count do not exist (fixed-grid launches queued before the count is known)
   uint32_t *heavy_count, *heavy_max;      // number of heavy tiles, largest candidate-row count among them
   uint32_t *heavy_list;                   // their tile ids (order of discovery)
   int32_t *heavy_slab;                    // [heavy tile][16][T] summed over the work items
+  // tiles in which a position may be covered by more than 255 rows (u8 counters): the LEAN kernel lists them and the
+  // general kernel -- launched right behind it with a fixed grid, no host round trip -- works through the list
+  uint32_t *deep_count, *deep_list;       // LEAN: where to list them (null: RowStats says there are none in this batch)
+  const uint32_t *tile_list, *tile_list_count;   // general kernel behind a lean one: the list to work through
   uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
   int64_t nrows;                          // rows of the batch (check build)
 };
@@ -742,12 +748,10 @@ __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td,
 //  work per tile weighs half as much, and 80 VGPRs for the five-chunk lane shapes)
 template <bool LEAN> constexpr int cx2_wg() { return LEAN ? 256 : CX_WG; }
 
-template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
-__global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN, cx2_wg<LEAN>()>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+// One tile: accumulate, then hand over (heavy / shared / deep tiles) or emit.
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, class LdsT>
+__device__ __forceinline__ void cx2_tile(const Cx2Args &a, int tile, const LdsT &L, uint32_t *s_scan, uint16_t *s_list, int *s_flag) {
   constexpr int WG = cx2_wg<LEAN>();
-  CX2_SHARED(T, NP, LEAN)
-  const int tile = cx_tile_of_block(blockIdx.x, ntiles);
-  if (tile >= ntiles) return;
   const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
   cx2_clear<T, NP, LEAN, WG>(L);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
@@ -760,6 +764,25 @@ __global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN
       a.tile_base[tile] = 0;
     }
     return;
+  }
+  if constexpr (LEAN) {
+    // u8 counters hold 255 rows per position.  Few enough candidate rows: safe.  Else the sorted starts decide: rows
+    // covering a position p all start before the end of the first of them, so if row x + 255 starts at or behind the end
+    // of row x for every candidate x, no position of the tile is covered by more than 255 rows (tiles.hip: k_row_stats
+    // asks the same of the whole batch).  A tile that fails goes to the general kernel's list.
+    if (a.deep_list && td.row_hi - td.row_lo > CX_FLUSH_ROWS) {
+      if (threadIdx.x == 0) *s_flag = 0;
+      __syncthreads();
+      bool deep = false;
+      for (int x = td.row_lo + (int)threadIdx.x; x + CX_FLUSH_ROWS < td.row_hi; x += WG)
+        deep |= (int64_t)a.c.start[x + CX_FLUSH_ROWS] < (int64_t)a.c.start[x] + (a.c.off[x + 1] - a.c.off[x]);
+      if (deep) *s_flag = 1;
+      __syncthreads();
+      if (*s_flag) {
+        if (threadIdx.x == 0) { a.deep_list[atomicAdd(a.deep_count, 1u)] = (uint32_t)tile; a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+        return;
+      }
+    }
   }
   __syncthreads();
   cx2_accumulate<T, G, NU, NP, FUSED, LEAN, WG>(a, td, td.row_lo, td.row_hi, L);
@@ -784,21 +807,43 @@ __global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN
   }
 }
 
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
+__global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN, cx2_wg<LEAN>()>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+  CX2_SHARED(T, NP, LEAN)
+  __shared__ int s_flag;
+  if constexpr (!LEAN) {
+    if (a.tile_list) {                                    // behind a lean launch: the tiles it listed, however many (fixed grid)
+      const uint32_t n = *a.tile_list_count;
+      for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        cx2_tile<T, G, NU, NP, FUSED, LEAN>(a, (int)a.tile_list[i], L, s_scan, s_list, &s_flag);
+        __syncthreads();                                  // (the next tile clears the arrays the emit just read)
+      }
+      return;
+    }
+  }
+  const int tile = cx_tile_of_block(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  cx2_tile<T, G, NU, NP, FUSED, LEAN>(a, tile, L, s_scan, s_list, &s_flag);
+}
+
 // One chunk of the candidate rows of one heavy tile: LDS sums as usual, then added into the tile's slab in HBM (or
 // straight into its shared slab slot when other ranks contribute too).
 template <int T, int G, int NU, int NP, bool FUSED>
 __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_heavy(Cx2Args a) {
   CX2_SHARED(T, NP, false)
-  const int tile = (int)a.heavy_list[blockIdx.y];
+  const uint32_t hi_idx = (uint32_t)a.heavy_first + blockIdx.y;
+  if (hi_idx >= *a.heavy_count) return;
+  const int tile = (int)a.heavy_list[hi_idx];
   const Tile td = a.tiles[tile];
-  const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
-  if (lo >= td.row_hi) return;
-  const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
-  cx2_clear<T, NP, false, CX_WG>(L);
-  __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED, false, CX_WG>(a, td, lo, hi, L);
-  cx2_dump_slab<T, NP, false, CX_WG>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
-                                        : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
+  for (int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk; lo < td.row_hi; lo += (int)gridDim.x * a.heavy_chunk) {
+    const int hi = td.row_hi - lo > a.heavy_chunk ? lo + a.heavy_chunk : td.row_hi;
+    cx2_clear<T, NP, false, CX_WG>(L);
+    __syncthreads();
+    cx2_accumulate<T, G, NU, NP, FUSED, false, CX_WG>(a, td, lo, hi, L);
+    cx2_dump_slab<T, NP, false, CX_WG>(L, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * T)
+                                          : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * T));
+    __syncthreads();
+  }
 }
 
 // Rule + rows of a tile whose sums sit in a slab: coverage difference arrays -> LDS, prefix sums, emit from HBM.
@@ -818,7 +863,9 @@ __device__ __forceinline__ void cx2_emit_from_slab(const Cx2Args &a, int tile, c
 
 template <int T, int NP>
 __global__ __launch_bounds__(CX_WG) void k_cx_emit_heavy(Cx2Args a) {
-  const int tile = (int)a.heavy_list[blockIdx.x];
+  const uint32_t hi_idx = (uint32_t)a.heavy_first + blockIdx.x;
+  if (hi_idx >= *a.heavy_count) return;
+  const int tile = (int)a.heavy_list[hi_idx];
   if (a.tiles[tile].slot >= 0) return;                     // emitted after the cross-rank reduce
   cx2_emit_from_slab<T, NP>(a, tile, a.heavy_slab + (int64_t)blockIdx.x * (kCxPlanes * T));
 }
@@ -974,21 +1021,25 @@ template <int G>
 __global__ __launch_bounds__(CX_WG, 8) void k_cxp_heavy(Cx2Args a, int np) {
   CXP_SHARED
   (void)s_scan; (void)s_list;
-  const int tile = (int)a.heavy_list[blockIdx.y];
-  Tile td = a.tiles[tile];
-  const int lo = td.row_lo + (int)blockIdx.x * a.heavy_chunk;
-  if (lo >= td.row_hi) return;
-  td.row_lo = lo;
-  if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
-  uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
-  for (int i = threadIdx.x; i < (8 * CXP_T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-  cxp_accumulate<G>(a.c, td, cnt);
-  __syncthreads();
-  cxp_convert(cnt);
-  __syncthreads();
-  cxp_dump_slab(a, cnt, np, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * CXP_T)
-                                          : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * CXP_T));
+  const uint32_t hi_idx = (uint32_t)a.heavy_first + blockIdx.y;
+  if (hi_idx >= *a.heavy_count) return;
+  const int tile = (int)a.heavy_list[hi_idx];
+  const Tile whole = a.tiles[tile];
+  for (int lo = whole.row_lo + (int)blockIdx.x * a.heavy_chunk; lo < whole.row_hi; lo += (int)gridDim.x * a.heavy_chunk) {
+    Tile td = whole;
+    td.row_lo = lo;
+    if (td.row_hi - lo > a.heavy_chunk) td.row_hi = lo + a.heavy_chunk;
+    uint4 *z = reinterpret_cast<uint4 *>(cnt_raw);
+    for (int i = threadIdx.x; i < (8 * CXP_T + 2 * kCxGuard) / 4; i += CX_WG) z[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    cxp_accumulate<G>(a.c, td, cnt);
+    __syncthreads();
+    cxp_convert(cnt);
+    __syncthreads();
+    cxp_dump_slab(a, cnt, np, td.slot >= 0 ? a.slab + (int64_t)td.slot * (kCxPlanes * CXP_T)
+                                            : a.heavy_slab + (int64_t)blockIdx.y * (kCxPlanes * CXP_T));
+    __syncthreads();
+  }
 }
 
 // One wavefront per tile copies the tile's rows from the pool to their place in the final table
@@ -1047,9 +1098,12 @@ static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
 }
 static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3; }
 
+constexpr unsigned CX_HEAVY_CAP = 8, CX_HEAVY_GRID = 128;   // ultra-deep tiles finished without a host round trip, work items each
+constexpr unsigned CX_LIST_GRID = 512;        // workgroups of the general kernel behind a lean launch (they loop over the list)
+
 template <int T, int NU, int NP, bool FUSED, bool LEAN>
 static void launch_cx_tiles(int g, int nt, hipStream_t s, const Cx2Args &a) {
-  const unsigned nb = (unsigned)(((nt + 7) / 8) * 8);
+  const unsigned nb = a.tile_list ? CX_LIST_GRID : (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
     case 4: if constexpr (FUSED || LEAN) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); } break;
     case 8: hipLaunchKernelGGL((k_cx_tiles<T, 8, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); break;
@@ -1287,9 +1341,12 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     ovf_base = 0;                                          // cursor, the pool sized by the rows actually produced
   }
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;           // misc[1] = pool cursor, misc[2] = nrow total
-  // u8 counters without folds when no position is covered by more than 255 rows (k_row_stats)
-  bool lean = np == 1 && st.deep == 0;
-  if (!options().cx_lean) lean = false;                    // test hook (EPIHIP_CX_LEAN=0): the general kernel
+  // Single-context reports run the LEAN kernel (u8 counters, no folds).  Where a position may be covered by more than
+  // 255 rows -- RowStats::deep says whether that can happen anywhere in the batch -- the lean kernel decides tile by tile
+  // and lists the deep ones for the general kernel, which is queued right behind it (no host round trip in between).
+  bool lean = np == 1;
+  if (!options().cx_lean) lean = false;                    // test hook (EPIHIP_CX_LEAN=0): the general kernel for every tile
+  const bool per_tile = lean && st.deep != 0;
   // lanes per row * 8 + chunks per lane; the heavy-tile kernel is the general one (three chunks per lane)
   const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused, lean);
   const int grp_heavy = np > 1 ? grp : pick_cx_shape(st.max_len, T, fused, false);
@@ -1305,11 +1362,17 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   if (options().heavy_rows > 0) a.heavy_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   if (a.heavy_rows > 16384) a.heavy_rows = 16384;          // u16 pairs and the packed coverage halves: a base adds at most 2
   a.heavy_chunk = a.heavy_rows / 4 > 64 ? a.heavy_rows / 4 : 64;
+  if (a.heavy_chunk > 256) a.heavy_chunk = 256;            // (a 20 000-row pile-up is then 80 work items, not 5)
   EPI_TRY(b->heavy_list.ensure((size_t)nt * 4));
   a.heavy_list = b->heavy_list.as<uint32_t>();
   a.heavy_count = b->misc.as<uint32_t>() + 3;             // misc[3] = heavy tiles, misc[8] = their largest row count
   a.heavy_max = b->misc.as<uint32_t>() + 8;
   a.heavy_slab = nullptr;
+  if (per_tile) {
+    EPI_TRY(b->deep_list.ensure((size_t)nt * 4));
+    a.deep_list = b->deep_list.as<uint32_t>();
+    a.deep_count = b->misc.as<uint32_t>() + 4;            // misc[4] = tiles handed from the lean to the general kernel
+  }
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;
   b->cx_last_slot = slot;
@@ -1330,12 +1393,34 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     a.pool_unmeth = b->pool_b.as<uint32_t>();
     a.pool_cap = (uint32_t)(b->pool_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b->pool_cap);
     if (attempt > 0) {                                   // (the tile-index pass zeroed them for the first attempt)
-      EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));         // cursor, total, heavy count
+      EPI_HIP(hipMemsetAsync(cursor, 0, 16, s));         // cursor, total, heavy count, deep count
       EPI_HIP(hipMemsetAsync(a.heavy_max, 0, 4, s));
     }
     prof_begin("cx_tiles", s);
     launch_cx(false, np, fused, lean, grp, nt, dim3(1), s, a);
     prof_end("cx_tiles", s);
+    if (per_tile) {                                      // the tiles the lean kernel listed, by the general kernel
+      Cx2Args g = a;
+      g.tile_list = a.deep_list;
+      g.tile_list_count = a.deep_count;
+      g.deep_list = nullptr; g.deep_count = nullptr;
+      prof_begin("cx_deep", s);
+      launch_cx(false, np, fused, false, grp_heavy, nt, dim3(1), s, g);
+      prof_end("cx_deep", s);
+    }
+    // Batches with deep positions may also hold ultra-deep tiles (set aside by the kernels above): the first CX_HEAVY_CAP of
+    // them are split, reduced and emitted by fixed-grid launches queued right here -- no host round trip for one pile-up
+    // in a WGS batch; a larger number is finished below, once the count is known.
+    const bool chained = st.deep != 0;
+    if (chained) {
+      EPI_TRY(b->heavy_slab.ensure((size_t)CX_HEAVY_CAP * kCxPlanes * T * 4));
+      a.heavy_slab = b->heavy_slab.as<int32_t>();
+      a.heavy_first = 0;
+      EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)CX_HEAVY_CAP * kCxPlanes * T * 4, s));
+      prof_begin("cx_heavy", s);
+      launch_cx(true, np, fused, lean, grp_heavy, nt, dim3(CX_HEAVY_GRID, CX_HEAVY_CAP), s, a);
+      prof_end("cx_heavy", s);
+    }
     EPI_HIP(hipGetLastError());
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -1346,9 +1431,12 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
       return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host9[0], nt);
     }
-    if (host[2] > 0) {
-      // ultra-deep tiles were set aside: split each over ceil(rows/chunk) workgroups, reduce in HBM, emit, rescan
-      const uint32_t nheavy = host[2], nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
+    const uint32_t heavy_done = chained ? CX_HEAVY_CAP : 0u;
+    if (host[2] > heavy_done) {
+      // ultra-deep tiles were set aside (and not finished above): split each over ceil(rows/chunk) workgroups, reduce in
+      // HBM, emit, rescan
+      const uint32_t nheavy = host[2] - heavy_done, nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
+      a.heavy_first = (int)heavy_done;
       EPI_TRY(b->heavy_slab.ensure((size_t)nheavy * kCxPlanes * T * 4));
       a.heavy_slab = b->heavy_slab.as<int32_t>();
       EPI_HIP(hipMemsetAsync(a.heavy_slab, 0, (size_t)nheavy * kCxPlanes * T * 4, s));

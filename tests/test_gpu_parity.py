@@ -420,6 +420,17 @@ def test_uniform_synth_medium_parity(ea):
     check_all(ea, synth_np.generate_uniform(n_total=20000), contexts=("CG", "CX"))
 
 
+@pytest.mark.parametrize("pile", [300, 700, 20000])
+def test_pileup_inside_a_wgs_stream(ea, pile):
+    """One amplicon-like pile-up in WGS-like data (bench cfg2p / cfg4d): the lean CX kernel keeps every ordinary tile and
+    lists only the tiles around the pile-up for the general kernel (a 20 000-row pile-up additionally takes the heavy-tile
+    split); the one-pass lMHL kernel folds its u8 counters there.  Fixed-length and ragged / gapped rows."""
+    n = 30000 + pile
+    check_all(ea, synth_np.generate_uniform(n_total=n, gap_every=0, ragged=False, pileup=(n // 2 + 77, pile)), mhl=True, contexts=("CG", "CX"))
+    if pile == 700:
+        check_all(ea, synth_np.generate_uniform(n_total=n, pileup=(5000, pile), seed=9), mhl=True, contexts=("CG",))
+
+
 @pytest.mark.parametrize("kw", [dict(n_total=20000, read_len=300), dict(n_total=6000, read_len=300, gap_from=150, gap_len=50),
                                 dict(n_total=300, read_len=10000, n_chr=2)])
 def test_synth_medium_parity(ea, kw):
