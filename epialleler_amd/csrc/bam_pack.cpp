@@ -17,6 +17,7 @@
 // usable (so it can be streamed to HBM with hipMemcpyAsync) and with malloc otherwise.
 #include <hip/hip_runtime.h>
 #include <zlib.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <limits.h>
 #include <fcntl.h>
@@ -107,27 +108,63 @@ int bgzf_scan(const uint8_t *in, size_t n, std::vector<Block> &blocks) {
   return EPI_OK;
 }
 
+// libdeflate (its shared library ships with the image; 2-3x zlib's inflate rate) is used when it can be loaded at run
+// time -- no headers needed for its three-call ABI -- and zlib otherwise.  Both produce the same bytes or an error.
+struct FastInflate {
+  void *(*alloc)() = nullptr;
+  int (*run)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+  void (*release)(void *) = nullptr;
+  FastInflate() {
+    if (epi::options().no_libdeflate) return;
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc = reinterpret_cast<void *(*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+    run = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(h, "libdeflate_deflate_decompress"));
+    release = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+    if (!alloc || !run || !release) { alloc = nullptr; run = nullptr; release = nullptr; }
+  }
+  bool ok() const { return run != nullptr; }
+};
+const FastInflate &fast_inflate() { static const FastInflate f; return f; }
+
 // Inflate blocks [b0, b1) to out + their upos, in parallel.
 int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size_t b0, size_t b1, uint8_t *out, int nthreads) {
   std::atomic<size_t> next(b0);
   std::atomic<int> bad(0);
   auto work = [&]() {
+    const FastInflate &fi = fast_inflate();
+    if (fi.ok()) {
+      void *d = fi.alloc();
+      if (d) {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= b1) break;
+          const Block &b = blocks[i];
+          if (b.ulen == 0) continue;
+          size_t got = 0;
+          if (fi.run(d, in + b.cpos, b.clen, out + b.upos, b.ulen, &got) != 0 || got != b.ulen) bad = 1;
+        }
+        fi.release(d);
+        return;
+      }
+    }
+    z_stream zs;                                             // one stream per thread, reset per block (an init / end pair per
+    memset(&zs, 0, sizeof(zs));                              // block allocates and frees its state and window every 64 KiB)
+    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= b1) break;
       const Block &b = blocks[i];
       if (b.ulen == 0) continue;
-      z_stream zs;
-      memset(&zs, 0, sizeof(zs));
-      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
+      if (inflateReset(&zs) != Z_OK) { bad = 1; continue; }
       zs.next_in = const_cast<Bytef *>(in + b.cpos);
       zs.avail_in = (uInt)b.clen;
       zs.next_out = out + b.upos;
       zs.avail_out = (uInt)b.ulen;
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
-      inflateEnd(&zs);
     }
+    inflateEnd(&zs);
   };
   int nt = nthreads > 0 ? nthreads : 1;
   if ((size_t)nt > b1 - b0) nt = b1 > b0 ? (int)(b1 - b0) : 1;
@@ -317,6 +354,21 @@ struct Packed {
   std::vector<uint8_t> bytes;
 };
 
+// (nt16 << 4) | ctx_idx(XM) of every query base of a record (src/epialleleR.h:28,32): two bases per byte of SEQ
+inline void packed_bytes(const Rec &r, const char *xm, std::vector<uint8_t> &pb) {
+  const size_t n = (size_t)r.l_seq;
+  pb.resize(n + 2);
+  uint8_t *__restrict__ o = pb.data();
+  const uint8_t *__restrict__ s = r.seq;
+  const unsigned char *__restrict__ x = reinterpret_cast<const unsigned char *>(xm);
+  for (size_t i = 0; i + 1 < n; i += 2) {
+    const uint8_t b = s[i >> 1];
+    o[i] = (uint8_t)((b & 0xF0) | (((x[i] + 2u) >> 2) & 15u));
+    o[i + 1] = (uint8_t)(((b << 4) & 0xF0) | (((x[i + 1] + 2u) >> 2) & 15u));
+  }
+  if (n & 1) o[n - 1] = (uint8_t)((s[(n - 1) >> 1] & 0xF0) | (((x[n - 1] + 2u) >> 2) & 15u));
+}
+
 // walk the CIGAR of one record into the template buffers; returns the reference position after the last op
 template <class F>
 int apply_cigar(const Rec &r, uint32_t dest0, F &&on_match, uint32_t *dest_end) {
@@ -416,6 +468,38 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   EPI_TRY(open_file(path, file));
   std::vector<Block> blocks;
   EPI_TRY(bgzf_scan(file.p, file.n, blocks));
+  // The output bytes go to page-locked memory (the upload DMAs straight from it).  Pinning ~100 MB takes tens of
+  // milliseconds, so it starts now, next to the inflate / pack work, sized by an estimate (a base is at least 2.5 bytes
+  // of record: half a byte of SEQ, QUAL, XM); a template set that turns out larger is allocated at the end instead.
+  struct PinAhead {
+    std::thread th;
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ok = false;
+    ~PinAhead() { release(); }
+    void wait() { if (th.joinable()) th.join(); }
+    void release() {
+      wait();
+#ifndef EPI_HOST_ONLY
+      if (ok && p) (void)hipHostFree(p);
+#endif
+      p = nullptr; ok = false;
+    }
+  } pin;
+#ifndef EPI_HOST_ONLY
+  {
+    size_t total = 0;
+    for (const Block &b : blocks) total += b.ulen;
+    if (total >= ((size_t)8 << 20)) {
+      pin.cap = (total / 2 + ((size_t)1 << 20) + 15) / 16 * 16;
+      pin.th = std::thread([&pin]() {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&pin.p, pin.cap, hipHostMallocDefault) == hipSuccess) pin.ok = true;
+        else (void)hipGetLastError();
+      });
+    }
+  }
+#endif
 
   // The file is processed in windows of inflated data (the reference streams records through HTSlib): inflate a run
   // of BGZF blocks, index the complete records, pack the complete templates, carry the rest (a record cut by the
@@ -444,6 +528,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   bool header_done = false, checked = false, paired = false, tMM = false;
   std::vector<std::string> names;
   std::vector<Rec> recs;
+  std::vector<size_t> roff;                                 // offsets of the window's records in buf
   size_t nrecs_total = 0;
   uint16_t skip_flags = 4;
   if (opt.skip_secondary) skip_flags |= 256;
@@ -545,7 +630,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   auto pack_pe = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
     const uint16_t skip_flags_pe = skip_flags | 8;
     const uint8_t q0 = (uint8_t)(opt.min_baseq - (opt.min_baseq > 0 ? 1 : 0));   // src/rcpp_read_bam.cpp:30,57
-    std::vector<uint8_t> tq(8192, q0), ts(8192, 0xFB);
+    std::vector<uint8_t> tq(8192, q0), ts(8192, 0xFB), pb;
     const char *tname = nullptr;
     int t_rname = 0, t_start = 0, t_strand = 0, t_width = 0;
     auto push_template = [&]() {                                                   // :61-69
@@ -578,13 +663,15 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
       uint32_t dest_end = 0;
       if (r.pos < t_start) return fail(EPI_ERR_ARG, "corrupt BAM record %s: starts before its template", r.qname);
       const uint32_t dest0 = (uint32_t)(r.pos - t_start);                                       // :118
+      packed_bytes(r, xm, pb);                                                                  // (nt16 << 4) | ctx_idx per query base
       EPI_TRY(apply_cigar(r, dest0, [&](uint32_t qpos, uint32_t dpos, uint32_t len) {
         if ((size_t)dpos + len > tq.size()) { tq.resize((size_t)dpos + len, q0); ts.resize((size_t)dpos + len, 0xFB); }
-        for (uint32_t j = 0; j < len; j++) {
-          if (r.qual[qpos + j] > tq[dpos + j]) {                                                // :127 strictly higher quality wins
-            tq[dpos + j] = r.qual[qpos + j];
-            ts[dpos + j] = (uint8_t)(seqi_shifted(r.seq, qpos + j) | ctx_idx(xm[qpos + j]));
-          }
+        const uint8_t *__restrict__ ql = r.qual + qpos, *__restrict__ pq = pb.data() + qpos;
+        uint8_t *__restrict__ tqd = tq.data() + dpos, *__restrict__ tsd = ts.data() + dpos;
+        for (uint32_t j = 0; j < len; j++) {                                                    // :127 strictly higher quality wins
+          const bool w = ql[j] > tqd[j];                                                        // (selects, not branches: the loop vectorises)
+          tqd[j] = w ? ql[j] : tqd[j];
+          tsd[j] = w ? pq[j] : tsd[j];
         }
       }, &dest_end));
       if (dest_end > 0x7FFFFFFFu) return fail(EPI_ERR_ARG, "corrupt BAM record %s: template too wide", r.qname);
@@ -595,7 +682,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     return EPI_OK;
   };
   auto pack_se = [&](size_t r_lo, size_t r_hi, Packed &P) -> int {
-    std::vector<uint8_t> buf;
+    std::vector<uint8_t> buf, pb;
     for (size_t ri = r_lo; ri < r_hi; ri++) {
       const Rec &r = recs[ri];
       if ((r.flag & skip_flags) || (int)r.mapq < opt.min_mapq) continue;                        // :240-241
@@ -610,10 +697,11 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
       }
       buf.assign(width, 0xFB);                                                                  // :265
       uint32_t dest_end = 0;
+      packed_bytes(r, xm, pb);
       EPI_TRY(apply_cigar(r, 0, [&](uint32_t qpos, uint32_t dpos, uint32_t len) {
-        for (uint32_t j = 0; j < len; j++)
-          if ((int)r.qual[qpos + j] >= opt.min_baseq)                                           // :278
-            buf[dpos + j] = (uint8_t)(seqi_shifted(r.seq, qpos + j) | ctx_idx(xm[qpos + j]));
+        const uint8_t *__restrict__ ql = r.qual + qpos, *__restrict__ pq = pb.data() + qpos;
+        uint8_t *__restrict__ bd = buf.data() + dpos;
+        for (uint32_t j = 0; j < len; j++) bd[j] = (int)ql[j] >= opt.min_baseq ? pq[j] : bd[j]; // :278
       }, &dest_end));
       P.rname.push_back(r.tid + 1);                                                             // :303-306
       P.strand.push_back(xg[0] == 'C' ? 1 : 2);
@@ -722,15 +810,33 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
       header_done = true;
       p = hdr_end;
     }
-    // index of the complete records of the window
+    // index of the complete records of the window: the chain of block sizes is walked by one thread (offsets only),
+    // the records are then parsed and validated by all of them
     recs.clear();
+    roff.clear();
     while (p + 4 <= buf.size()) {
       const uint32_t bs = rd32(buf.data() + p);
       if (p + 4 + (size_t)bs > buf.size()) break;            // cut by the window (or by the end of the file)
-      Rec r;
-      if (!parse_record(buf.data() + p + 4, bs, &r)) return fail(EPI_ERR_ARG, "corrupt BAM record");
-      recs.push_back(r);
+      roff.push_back(p);
       p += 4 + (size_t)bs;
+    }
+    recs.resize(roff.size());
+    {
+      const size_t nrec = roff.size();
+      size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
+      if (nrec < 4096) K = 1;
+      std::atomic<int> bad(0);
+      auto parse = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+          const uint8_t *q = buf.data() + roff[i];
+          if (!parse_record(q + 4, rd32(q), &recs[i])) { bad = 1; return; }
+        }
+      };
+      std::vector<std::thread> th;
+      for (size_t k = 1; k < K; k++) th.emplace_back(parse, nrec * k / K, nrec * (k + 1) / K);
+      parse(0, nrec / K);
+      for (auto &t : th) t.join();
+      if (bad) return fail(EPI_ERR_ARG, "corrupt BAM record");
     }
     if (final && p != buf.size()) return fail(EPI_ERR_ARG, "truncated BAM record");
     if (!checked) {
@@ -813,14 +919,21 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   }
   size_t nbytes = 0;
   for (size_t i = 0; i < n; i++) nbytes += (size_t)len[i];
-  const size_t cap = (nbytes + 15) / 16 * 16 + 64;
+  size_t cap = (nbytes + 15) / 16 * 16 + 64;
   void *xmp = nullptr;
 #ifdef EPI_HOST_ONLY
   xmp = malloc(cap); out->pinned = 0;                      // host-only sanitizer build (`make asan`)
 #else
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&xmp, cap, hipHostMallocDefault) == hipSuccess) out->pinned = 1;
-  else { (void)hipGetLastError(); xmp = malloc(cap); out->pinned = 0; }
+  pin.wait();
+  if (pin.ok && pin.cap >= cap) {                          // the buffer pinned while the file was being read
+    xmp = pin.p; cap = pin.cap; out->pinned = 1;
+    pin.p = nullptr; pin.ok = false;
+  } else {
+    pin.release();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&xmp, cap, hipHostMallocDefault) == hipSuccess) out->pinned = 1;
+    else { (void)hipGetLastError(); xmp = malloc(cap); out->pinned = 0; }
+  }
 #endif
   out->xm = (uint8_t *)xmp;
   out->off = (int64_t *)malloc((n + 1) * sizeof(int64_t));
@@ -850,7 +963,11 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     run(0);
     for (auto &t : th) t.join();
   }
-  memset(out->xm + w, 0xFB, cap - (size_t)w);
+  // 0xFB padding up to the 16-byte boundary the kernels may read to, plus a little (a buffer pinned ahead can be much
+  // larger than the templates: its tail stays untouched and is not part of xm_capacity)
+  const size_t padded = ((size_t)w + 15) / 16 * 16 + 64;
+  memset(out->xm + w, 0xFB, padded - (size_t)w);
+  cap = padded;
   lap("sort+copy");
   out->n = (int64_t)n;
   out->nbytes = w;

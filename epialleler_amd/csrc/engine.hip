@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -146,21 +147,73 @@ int epi_engine_device(const epi_engine *e) { return e ? e->device : -1; }
 
 // Host -> HBM through two pinned staging buffers: the CPU fills buffer k+1
 // while the DMA engine drains buffer k (hipMemcpyAsync on the copy stream).
-// memcpy into a pinned staging buffer with a few threads: one core copies ~12 GB/s, the link takes ~55
+// memcpy between pageable memory and a pinned staging buffer with a few threads (one core copies ~12 GB/s, the link takes
+// ~55; first-touch page faults of a fresh destination spread over the threads too).  The workers are a small persistent
+// pool: spawning threads per 8 MiB piece cost more than the copies.
+namespace {
+struct CopyPool {
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  char *dst = nullptr;
+  const char *src = nullptr;
+  size_t len = 0, part = 0;
+  unsigned parts = 0, next = 0, pending = 0;
+  uint64_t epoch = 0;
+  bool stop = false;
+
+  void run_part(unsigned i) {
+    const size_t o = part * i;
+    if (o < len) memcpy(dst + o, src + o, o + part > len ? len - o : part);
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&]() { return stop || (epoch != seen && next < parts); });
+      if (stop) return;
+      while (next < parts) {
+        const unsigned i = next++;
+        lk.unlock();
+        run_part(i);
+        lk.lock();
+        if (--pending == 0) cv_done.notify_all();
+      }
+      seen = epoch;
+    }
+  }
+  void copy(void *d, const void *s, size_t n, unsigned k) {
+    std::unique_lock<std::mutex> lk(mu);
+    while (workers.size() + 1 < k) workers.emplace_back([this]() { worker(); });
+    dst = static_cast<char *>(d); src = static_cast<const char *>(s); len = n;
+    part = ((n + k - 1) / k + 4095) & ~(size_t)4095;       // k * part >= n
+    parts = k; next = 0; pending = k; epoch++;
+    cv_work.notify_all();
+    while (next < parts) {                                  // the caller takes parts too
+      const unsigned i = next++;
+      lk.unlock();
+      run_part(i);
+      lk.lock();
+      --pending;
+    }
+    cv_done.wait(lk, [&]() { return pending == 0; });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_work.notify_all();
+    for (auto &t : workers) t.join();
+  }
+};
+}  // namespace
+
 static void parallel_memcpy(void *dst, const void *src, size_t len) {
   static const unsigned hw = std::thread::hardware_concurrency();
-  const unsigned k = len < (4u << 20) ? 1u : (hw >= 8 ? 4u : hw >= 4 ? 2u : 1u);
+  const unsigned k = len < (2u << 20) ? 1u : (hw >= 16 ? 8u : hw >= 8 ? 4u : hw >= 4 ? 2u : 1u);
   if (k == 1) { memcpy(dst, src, len); return; }
-  const size_t part = ((len + k - 1) / k + 4095) & ~(size_t)4095;   // k * part >= len (len / k dropped up to k - 1 tail bytes)
-  std::vector<std::thread> th;
-  for (unsigned i = 1; i < k; i++) {
-    const size_t o = part * i;
-    if (o >= len) break;
-    const size_t l = o + part > len ? len - o : part;
-    th.emplace_back([=]() { memcpy(static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, l); });
-  }
-  memcpy(dst, src, part < len ? part : len);
-  for (auto &t : th) t.join();
+  static CopyPool pool;                                     // (one copy at a time: the engine's calls are serialised by contract)
+  static std::mutex one;
+  std::lock_guard<std::mutex> g(one);
+  pool.copy(dst, src, len, k);
 }
 
 // true when h_src is page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister, e.g. the producer's

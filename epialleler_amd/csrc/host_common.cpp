@@ -54,6 +54,7 @@ static void read_options() {
   geti("EPIHIP_PR_RPG", &o.pr_rpg);
   if (const char *e = getenv("EPIHIP_PR_WIDE")) o.pr_wide = atoi(e) != 0;
   o.bam_timing = getenv("EPIHIP_BAM_TIMING") != nullptr;
+  o.no_libdeflate = getenv("EPIHIP_NO_LIBDEFLATE") != nullptr;
   g_options = o;
 }
 

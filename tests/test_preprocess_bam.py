@@ -221,3 +221,26 @@ def test_host_columns_outlive_the_processed_bam(ea):
     del xm
     gc.collect()
     assert np.array_equal(sl, ref["xm"][100:200])
+
+
+def test_both_inflaters_give_the_same_table(ea, tmp_path):
+    """BGZF blocks are inflated by libdeflate when its shared library can be loaded (it ships with the image) and by zlib
+    otherwise (EPIHIP_NO_LIBDEFLATE forces zlib): same bytes either way, and a corrupt block is an error either way."""
+    import subprocess
+    import sys
+    path = os.path.join(BAM, "capture.bam")
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import epialleler_amd as ea; b = ea.preprocessBam(%r, nthreads=3); "
+            "print(hashlib.sha256(b''.join(bytes(memoryview(b.host[k])) for k in ('xm','off','rname','strand','start'))).hexdigest())"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path))
+    outs = []
+    for env in ({}, {"EPIHIP_NO_LIBDEFLATE": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=e).decode().strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0xFF                                  # damage the compressed data of some block
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        ea.preprocessBam(str(bad))
