@@ -41,7 +41,15 @@ using namespace epi;
 
 namespace {
 
-struct Block { size_t cpos, clen; size_t upos, ulen; };   // compressed payload / uncompressed placement
+struct Block {
+  size_t cpos, clen; size_t upos, ulen;                     // compressed payload / uncompressed placement
+  // what the inflating thread found when it walked the block's bytes as a chain of BAM records starting at the block's
+  // first byte: their number, and whether the chain ends exactly at the block's end.  (HTSlib never lets a record
+  // straddle two blocks unless it is larger than one, so this is the true chain nearly always -- the index uses it
+  // only where the true chain does arrive at the block's first byte.)
+  uint32_t spec_n = 0;
+  bool spec_ok = false;
+};
 
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -128,9 +136,22 @@ struct FastInflate {
 const FastInflate &fast_inflate() { static const FastInflate f; return f; }
 
 // Inflate blocks [b0, b1) to out + their upos, in parallel.
-int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size_t b0, size_t b1, uint8_t *out, int nthreads) {
+int bgzf_inflate_range(const uint8_t *in, std::vector<Block> &blocks, size_t b0, size_t b1, uint8_t *out, int nthreads) {
   std::atomic<size_t> next(b0);
   std::atomic<int> bad(0);
+  auto walk = [&](Block &b) {                                // (the bytes are still in this core's cache)
+    const uint8_t *q = out + b.upos;
+    size_t p = 0;
+    uint32_t n = 0;
+    while (p + 4 <= b.ulen) {
+      const size_t bs = rd32(q + p);
+      if (p + 4 + bs > b.ulen) break;
+      p += 4 + bs;
+      n++;
+    }
+    b.spec_n = n;
+    b.spec_ok = p == b.ulen;
+  };
   auto work = [&]() {
     const FastInflate &fi = fast_inflate();
     if (fi.ok()) {
@@ -139,10 +160,12 @@ int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size
         for (;;) {
           const size_t i = next.fetch_add(1);
           if (i >= b1) break;
-          const Block &b = blocks[i];
+          Block &b = blocks[i];
+          b.spec_n = 0; b.spec_ok = false;
           if (b.ulen == 0) continue;
           size_t got = 0;
           if (fi.run(d, in + b.cpos, b.clen, out + b.upos, b.ulen, &got) != 0 || got != b.ulen) bad = 1;
+          else walk(b);
         }
         fi.release(d);
         return;
@@ -154,7 +177,8 @@ int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= b1) break;
-      const Block &b = blocks[i];
+      Block &b = blocks[i];
+      b.spec_n = 0; b.spec_ok = false;
       if (b.ulen == 0) continue;
       if (inflateReset(&zs) != Z_OK) { bad = 1; continue; }
       zs.next_in = const_cast<Bytef *>(in + b.cpos);
@@ -163,6 +187,7 @@ int bgzf_inflate_range(const uint8_t *in, const std::vector<Block> &blocks, size
       zs.avail_out = (uInt)b.ulen;
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+      else walk(b);
     }
     inflateEnd(&zs);
   };
@@ -527,7 +552,26 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   size_t carry = 0, bi = 0, hdr_end = 0;
   bool header_done = false, checked = false, paired = false, tMM = false;
   std::vector<std::string> names;
-  std::vector<Rec> recs;
+  struct RecBuf {                                           // the window's records (not value-initialised: 80 bytes x millions)
+    Rec *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RecBuf() { free(p); }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    Rec &operator[](size_t i) { return p[i]; }
+    const Rec &operator[](size_t i) const { return p[i]; }
+    const Rec *begin() const { return p; }
+    const Rec *end() const { return p + n; }
+    void resize_uninit(size_t m) {
+      if (m > cap) {
+        free(p);
+        p = static_cast<Rec *>(malloc((m + m / 8 + 16) * sizeof(Rec)));
+        if (!p) { cap = 0; n = 0; throw std::bad_alloc(); }
+        cap = m + m / 8 + 16;
+      }
+      n = m;
+    }
+  } recs;
   std::vector<size_t> roff;                                 // offsets of the window's records in buf
   size_t nrecs_total = 0;
   uint16_t skip_flags = 4;
@@ -773,6 +817,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   // ---- the windows ----
   for (bool final = blocks.empty(); ;) {
     size_t b1 = bi, add = 0;
+    const size_t win_b0 = bi;                                // first block inflated into this window
     while (b1 < blocks.size() && (b1 == bi || add + blocks[b1].ulen <= window)) { blocks[b1].upos = carry + add; add += blocks[b1].ulen; b1++; }
     final = b1 == blocks.size();
     buf.resize(carry + add);
@@ -810,31 +855,60 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
       header_done = true;
       p = hdr_end;
     }
-    // index of the complete records of the window: the chain of block sizes is walked by one thread (offsets only),
-    // the records are then parsed and validated by all of them
-    recs.clear();
-    roff.clear();
-    while (p + 4 <= buf.size()) {
-      const uint32_t bs = rd32(buf.data() + p);
-      if (p + 4 + (size_t)bs > buf.size()) break;            // cut by the window (or by the end of the file)
-      roff.push_back(p);
-      p += 4 + (size_t)bs;
-    }
-    recs.resize(roff.size());
+    // Index of the complete records of the window.  The chain of block sizes is followed from the first record; wherever
+    // it arrives exactly at the first byte of a BGZF block whose own walk (done by the thread that inflated it) ended
+    // exactly at the block's end, the block's records are taken as a whole -- they are enumerated and parsed by all
+    // threads below -- so the serial part is one step per block, not per record.
+    struct Span { size_t p; uint32_t n; };                  // n records starting at byte p (a block, or a single record)
+    std::vector<Span> spans;
+    size_t nrec = 0;
     {
-      const size_t nrec = roff.size();
+      size_t kb = win_b0;
+      for (;;) {
+        while (kb < bi && blocks[kb].upos < p) kb++;
+        if (kb < bi && blocks[kb].upos == p && blocks[kb].spec_ok && blocks[kb].spec_n > 0) {
+          spans.push_back({p, blocks[kb].spec_n});
+          nrec += blocks[kb].spec_n;
+          p += blocks[kb].ulen;
+          continue;
+        }
+        if (p + 4 > buf.size()) break;
+        const uint32_t bs = rd32(buf.data() + p);
+        if (p + 4 + (size_t)bs > buf.size()) break;          // cut by the window (or by the end of the file)
+        spans.push_back({p, 1u});
+        nrec++;
+        p += 4 + (size_t)bs;
+      }
+    }
+    recs.resize_uninit(nrec);
+    roff.resize(nrec);
+    {
+      std::vector<size_t> base(spans.size() + 1, 0);
+      for (size_t i = 0; i < spans.size(); i++) base[i + 1] = base[i] + spans[i].n;
       size_t K = opt.nthreads > 1 ? (size_t)(opt.nthreads > 16 ? 16 : opt.nthreads) : 1;
       if (nrec < 4096) K = 1;
+      std::atomic<size_t> next(0);
       std::atomic<int> bad(0);
-      auto parse = [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; i++) {
-          const uint8_t *q = buf.data() + roff[i];
-          if (!parse_record(q + 4, rd32(q), &recs[i])) { bad = 1; return; }
+      auto parse = [&]() {
+        for (;;) {
+          const size_t i0 = next.fetch_add(16);              // a few spans at a time
+          if (i0 >= spans.size()) break;
+          const size_t i1 = i0 + 16 < spans.size() ? i0 + 16 : spans.size();
+          for (size_t i = i0; i < i1; i++) {
+            size_t q = spans[i].p;
+            for (size_t j = base[i]; j < base[i + 1]; j++) {
+              const uint8_t *rp = buf.data() + q;
+              const uint32_t bs = rd32(rp);
+              roff[j] = q;
+              if (!parse_record(rp + 4, bs, &recs[j])) { bad = 1; return; }
+              q += 4 + (size_t)bs;
+            }
+          }
         }
       };
       std::vector<std::thread> th;
-      for (size_t k = 1; k < K; k++) th.emplace_back(parse, nrec * k / K, nrec * (k + 1) / K);
-      parse(0, nrec / K);
+      for (size_t k = 1; k < K; k++) th.emplace_back(parse);
+      parse();
       for (auto &t : th) t.join();
       if (bad) return fail(EPI_ERR_ARG, "corrupt BAM record");
     }
@@ -875,7 +949,7 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     }
     EPI_TRY(pack_window(r_end));
     nrecs_total += r_end;
-    const size_t keep_from = r_end < recs.size() ? (size_t)(reinterpret_cast<const uint8_t *>(recs[r_end].qname) - 36 - buf.data()) : p;
+    const size_t keep_from = r_end < recs.size() ? roff[r_end] : p;
     carry = buf.size() - keep_from;
     if (carry) memmove(buf.data(), buf.data() + keep_from, carry);
     hdr_end = 0;                                             // (the header is gone from the buffer)

@@ -244,3 +244,32 @@ def test_both_inflaters_give_the_same_table(ea, tmp_path):
     bad.write_bytes(bytes(raw))
     with pytest.raises(ValueError):
         ea.preprocessBam(str(bad))
+
+
+@pytest.mark.parametrize("blk", [777, 5000, 65280])
+def test_records_straddling_bgzf_blocks(ea, tmp_path, blk):
+    """HTSlib keeps a record inside one BGZF block, and the index takes such blocks as a whole (each walked by the thread
+    that inflated it).  A file whose blocks cut records anywhere -- legal BGZF -- must give the same table: the index then
+    follows the chain record by record until it meets a block boundary again."""
+    import gzip
+    import struct
+    import zlib
+    path = os.path.join(BAM, "capture.bam")
+    raw = gzip.open(path, "rb").read()
+
+    def block(data):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    out = tmp_path / "reblocked.bam"
+    with open(out, "wb") as f:
+        for o in range(0, len(raw), blk):
+            f.write(block(raw[o:o + blk]))
+        f.write(block(b""))
+    want = ea.preprocessBam(path).host
+    for nt, win in ((1, 0), (5, 0), (3, 64)):
+        got = ea.preprocessBam(str(out), nthreads=nt, window_kib=win).host
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (k, blk, nt, win)
