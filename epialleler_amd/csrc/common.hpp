@@ -194,6 +194,7 @@ struct Options {
   int pr_rpg = 0;            // EPIHIP_PR_RPG
   int pr_wide = 1;           // EPIHIP_PR_WIDE=0
   int bam_timing = 0;        // EPIHIP_BAM_TIMING    phase times of the BAM reader on stderr
+  int no_hugepage = 0;       // EPIHIP_NO_HUGEPAGE   plain malloc for the BAM reader's large buffers (A/B runs)
   int no_libdeflate = 0;     // EPIHIP_NO_LIBDEFLATE zlib's inflate for the BGZF blocks although libdeflate.so.0 can be loaded
 };
 const Options &options();

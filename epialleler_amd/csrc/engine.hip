@@ -419,16 +419,15 @@ void epi_batch_free(epi_batch *b) {
 
 int64_t epi_batch_nrows(const epi_batch *b) { return b ? b->n : -1; }
 
-void epi_cx_table_free(epi_cx_table *t) {
+void epi_cx_table_free(epi_cx_table *t) {                // (the columns are one allocation, capi.hip: rname is its start)
   if (!t) return;
-  free(t->rname); free(t->strand); free(t->pos); free(t->context); free(t->meth); free(t->unmeth);
+  free(t->rname);
   memset(t, 0, sizeof(*t));
 }
 
-void epi_mhl_table_free(epi_mhl_table *t) {
+void epi_mhl_table_free(epi_mhl_table *t) {              // (one allocation: length is its start)
   if (!t) return;
-  free(t->rname); free(t->strand); free(t->pos); free(t->context); free(t->coverage);
-  free(t->length); free(t->lmhl);
+  free(t->length);
   memset(t, 0, sizeof(*t));
 }
 

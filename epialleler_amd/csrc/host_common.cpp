@@ -55,6 +55,7 @@ static void read_options() {
   if (const char *e = getenv("EPIHIP_PR_WIDE")) o.pr_wide = atoi(e) != 0;
   o.bam_timing = getenv("EPIHIP_BAM_TIMING") != nullptr;
   o.no_libdeflate = getenv("EPIHIP_NO_LIBDEFLATE") != nullptr;
+  o.no_hugepage = getenv("EPIHIP_NO_HUGEPAGE") != nullptr;
   g_options = o;
 }
 

@@ -66,6 +66,7 @@ typedef struct {
   double *length, *lmhl;
 } epi_mhl_table;
 
+/* (The columns of a table are one allocation: release a table only through these, never column by column.) */
 void epi_cx_table_free(epi_cx_table *t);
 void epi_mhl_table_free(epi_mhl_table *t);
 
