@@ -189,7 +189,7 @@ struct Options {
   int mhl_multi = 0;         // EPIHIP_MHL_MULTI     wavefront-per-read pass 1
   int mhl_group_g = 0, mhl_group_c = 0;   // EPIHIP_MHL_GROUP="G,C"
   int mhl_sums = 0;          // EPIHIP_MHL_SUMS      32 / 64
-  int mhlf_shape = 0;        // EPIHIP_MHLF_SHAPE="G,C"  lane shape of the one-pass lMHL kernel, as G * 8 + C
+  int mhlf_shape = 0;        // EPIHIP_MHLF_SHAPE="G,CA[,CB]"  lane shape of the one-pass lMHL kernel, as G * 100 + CA * 10 + CB
   int pr_group = 0;          // EPIHIP_GROUP         lanes per read of the general per-read kernel
   int pr_rpg = 0;            // EPIHIP_PR_RPG
   int pr_wide = 1;           // EPIHIP_PR_WIDE=0

@@ -47,8 +47,11 @@ static void read_options() {
   if (const char *e = getenv("EPIHIP_MHL_GROUP")) { int g = 0, c = 0; if (sscanf(e, "%d,%d", &g, &c) == 2) { o.mhl_group_g = g; o.mhl_group_c = c; } else o.mhl_group_g = -1; }
   geti("EPIHIP_MHL_SUMS", &o.mhl_sums);
   if (const char *e = getenv("EPIHIP_MHLF_SHAPE")) {
-    int g = 0, c = 0;
-    if (sscanf(e, "%d,%d", &g, &c) == 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && c >= 2 && c <= 4) o.mhlf_shape = g * 8 + c;
+    int g = 0, ca = 0, cb = 0;
+    const int nf = sscanf(e, "%d,%d,%d", &g, &ca, &cb);
+    const bool two = nf == 3 && cb == 2 && ca == 3 && g >= 4 && g <= 32;
+    if (nf >= 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && ca >= 2 && ca <= 4 && (nf == 2 || cb == 0 || two))
+      o.mhlf_shape = g * 100 + ca * 10 + (nf == 3 ? cb : 0);
   }
   geti("EPIHIP_GROUP", &o.pr_group);
   geti("EPIHIP_PR_RPG", &o.pr_rpg);

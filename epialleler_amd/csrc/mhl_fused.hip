@@ -46,6 +46,7 @@ namespace epi {
 #define EPI_MHLF_ABLATE 0                         // 1: no emit, 2: no row analysis (loads only), 4: no stretch runs, 8: no call counters
 #endif
 constexpr int MHLF_WG = EPI_MHLF_WG, MHLF_NW = MHLF_WG / 64, MHLF_Q = MHLF_T / 4;
+constexpr int MHLF_WG2 = 256;                     // workgroup of the two-block lane shapes
 constexpr int MHLF_FOLD = 255;                    // u8 call counters: a row adds at most 1 per position
 constexpr int MHLF_FAST_ROWS = 32767;             // packed u16 coverage halves / u16 folded counters of the fast variant
 
@@ -304,9 +305,9 @@ __device__ __forceinline__ void mhlf_seg_scan(uint32_t &pf, uint32_t &sf, int su
 }
 
 // u8 call counters -> the wide ones (u16 pairs / u32), every MHLF_FOLD rows
-template <bool WIDE>
+template <bool WIDE, int WG>
 __device__ __forceinline__ void mhlf_fold(uint32_t *s_n8, uint32_t *s_nw) {
-  for (int i = threadIdx.x; i < 2 * MHLF_Q; i += MHLF_WG) {
+  for (int i = threadIdx.x; i < 2 * MHLF_Q; i += WG) {
     const uint32_t v = s_n8[i];
     if (v == 0u) continue;
     s_n8[i] = 0u;
@@ -349,10 +350,10 @@ __device__ __forceinline__ void mhlf_scan_array(X *arr, int lane) {
 // Prefix sums of the difference arrays, the rule (a row iff n > cov/2), ordered rows into the tile's pool slot.
 //  fast layout: s_cov u32 [T] ('+' in the low half, '-' in the high), calls in s_n8 (u8) or, folded, s_nw (u16 pairs)
 //  WIDE layout: s_cov u32 [2][T], calls in s_n8 or, folded, s_nw u32 [2][T]
-template <bool WIDE, class ST>
+template <bool WIDE, class ST, int WG>
 __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool folded, const uint32_t *s_n8, const uint32_t *s_nw,
                                           uint32_t *s_cov, ST *s_sum, uint32_t *s_scan) {
-  constexpr int T = MHLF_T, Q = MHLF_Q, NW = MHLF_NW, PPT = T / MHLF_WG;
+  constexpr int T = MHLF_T, Q = MHLF_Q, NW = WG / 64, PPT = T / WG;
   static_assert(PPT == 2 || PPT == 4 || PPT == 8, "emit layout: 2, 4 or 8 consecutive positions per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // difference arrays -> sums, in place: the arrays are dealt round-robin to the wavefronts
@@ -429,13 +430,13 @@ __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool fold
 }
 
 // raw arrays of a tile that other ranks contribute to -> its slot of the slabs (summed across ranks by the caller)
-template <bool WIDE, class ST>
+template <bool WIDE, class ST, int WG>
 __device__ __forceinline__ void mhlf_dump_slab(const MhlFArgs &a, int slot, bool folded, const uint32_t *s_n8, const uint32_t *s_nw,
                                                const uint32_t *s_cov, const ST *s_sum) {
   constexpr int T = MHLF_T, Q = MHLF_Q;
   int32_t *cnt = a.slab_cnt + (int64_t)slot * (MHLF_CNT_PLANES * T);
   unsigned long long *sum = a.slab_sum + (int64_t)slot * (MHLF_SUM_PLANES * T);
-  for (int i = threadIdx.x; i < 2 * T; i += MHLF_WG) {
+  for (int i = threadIdx.x; i < 2 * T; i += WG) {
     const int s = i / T, p = i % T;
     uint32_t n;
     if (!folded) n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
@@ -451,7 +452,7 @@ __device__ __forceinline__ void mhlf_dump_slab(const MhlFArgs &a, int slot, bool
     }
     if (d) atomicAdd(cnt + (2 + s) * T + p, d);
   }
-  for (int i = threadIdx.x; i < MHLF_SUM_PLANES * T; i += MHLF_WG) {
+  for (int i = threadIdx.x; i < MHLF_SUM_PLANES * T; i += WG) {
     const ST v = s_sum[i];
     if (v == (ST)0) continue;
     unsigned long long x;
@@ -462,11 +463,61 @@ __device__ __forceinline__ void mhlf_dump_slab(const MhlFArgs &a, int slot, bool
 
 template <bool WIDE> constexpr int mhlf_lds_words() { return WIDE ? 2 * MHLF_T : MHLF_T; }
 
-template <int G, int C, bool WIDE>
-__global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fused(MhlFArgs a, int ntiles) {
-  using M = typename MaskOf<C>::T;
+// What one block of a lane's bytes (W of them, starting at tile position P0) adds for a kept row: S(M) over its pieces of
+// the methylated stretches, the call counters of its pairs of dwords and -- rows with skipped bytes -- h and S(h) per
+// counted run and the coverage correction.
+template <class ST> struct MhlfRow {
+  ST *dn, *dh, *dd;                       // difference arrays of S(M), h, S(h) of the row's strand
+  uint32_t *covp, *n8;                    // coverage array (of the strand, WIDE) and u8 call counters of the strand
+  uint32_t unit, h, H;
+  unsigned long long sh;                  // S(h)
+  bool anyk;
+};
+template <int W, int NPAIR, class M, class ST>
+__device__ __forceinline__ void mhlf_block(const MhlfRow<ST> &c, M U, M L, M K, uint32_t enter, uint32_t cont, int32_t P0,
+                                           const uint32_t (&np)[NPAIR], int vlo, int vhi) {
+  // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
+  const M P = (EPI_MHLF_ABLATE & 4) ? (M)0 : mhlf_span_bits<W, M>(U, L, K, enter, cont);
+  mhlf_for_runs<W, M>(P, true, U, L, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(c.dn, P0 + f, P0 + f + e, mhl_lut(m, c.H)); });
+  // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any
+  unsigned long long *n8 = reinterpret_cast<unsigned long long *>(c.n8 + (P0 >> 2));
+#pragma unroll
+  for (int e = 0; e < NPAIR; e++) {                        // (P0 is a multiple of 16: a pair is in or out of the tile together)
+    if (np[e] != 0u && (uint32_t)((P0 >> 2) + 2 * e) < (uint32_t)MHLF_Q && !(EPI_MHLF_ABLATE & 8))
+      atomicAdd(n8 + e, (unsigned long long)((np[e] >> 3) & 0x01010101u) | ((unsigned long long)((np[e] >> 7) & 0x01010101u) << 32));
+  }
+  if (__builtin_expect(c.anyk, 0)) {
+    // reads with skipped bytes: h and S(h) per counted run, coverage -1 over the skipped runs
+    const M V = vhi > vlo ? bm_below<M>(vhi) & ~bm_below<M>(vlo) : (M)0;       // (lanes behind the row's end: nothing)
+    mhlf_for_runs<W, M>(V & ~K, false, U, L, enter, cont, [&](int f, int e, uint32_t) {
+      mhlf_interval(c.dh, P0 + f, P0 + f + e, (unsigned long long)c.h);
+      mhlf_interval(c.dd, P0 + f, P0 + f + e, c.sh);
+    });
+    mhlf_for_runs<W, M>(K, false, U, L, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(c.covp, P0 + f, P0 + f + e, (unsigned long long)(0u - c.unit)); });
+  }
+}
+
+// segmented-scan elements of one block: (saw a cut, members after the last cut) and (saw a cut, members before the first)
+template <class M>
+__device__ __forceinline__ void mhlf_block_seg(M U, M L, uint32_t &pf, uint32_t &sf) {
+  const uint32_t has = L ? 0x80000000u : 0u;
+  pf = has | (uint32_t)bm_popc(U & (L ? ~bm_below<M>(bm_msb(L) + 1) : ~(M)0));
+  sf = has | (uint32_t)bm_popc(U & (L ? ((L & ((M)0 - L)) - (M)1) : ~(M)0));
+}
+
+template <bool WIDE, int WG> constexpr int mhlf_wps() { return WIDE ? (WG >= 512 ? 4 : 2) : (WG >= 512 ? EPI_MHLF_WPS : 4); }
+
+// G lanes own a row.  A lane holds 16 * (CA + CB) contiguous bytes as one or two mask blocks: CB = 0 is one block of up to
+// 64 bytes (64-bit masks); CA = 3, CB = 2 is 80 bytes as a 48-byte and a 32-byte block, each with masks of its own, the
+// two combined like two lanes before the lane scans -- 4 lanes x 80 bytes hold a PE150 template (16 rows per wavefront
+// step where 8 lanes x 48 bytes hold 8: the work that is per lane, not per byte, halves per row).
+template <int G, int CA, int CB, bool WIDE, int WG>
+__global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFArgs a, int ntiles) {
+  static_assert(!(WIDE && CB), "the WIDE variant is built with one block per lane");
+  using MA = typename MaskOf<CA>::T;
+  using MB = uint32_t;                                     // CB <= 2
   using ST = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;
-  constexpr int W = 16 * C, T = MHLF_T, Q = MHLF_Q, R = 64 / G, NW = MHLF_NW;
+  constexpr int C = CA + CB, WA = 16 * CA, WB = 16 * CB, W = 16 * C, T = MHLF_T, Q = MHLF_Q, R = 64 / G, NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t s_n8[2 * Q];                      // [strand][Q]: calls of the context, u8 x 4 positions
   __shared__ __attribute__((aligned(16))) uint32_t s_nw[mhlf_lds_words<WIDE>()];     // the same, folded every 255 rows
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[mhlf_lds_words<WIDE>()];    // coverage difference array(s)
@@ -490,15 +541,15 @@ __global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fuse
   }
   {
     uint4 *z = reinterpret_cast<uint4 *>(s_n8);
-    for (int i = threadIdx.x; i < 2 * Q / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < 2 * Q / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
     if (nrows > MHLF_FOLD) {
       z = reinterpret_cast<uint4 *>(s_nw);
-      for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+      for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
     }
     z = reinterpret_cast<uint4 *>(s_cov);
-    for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
     z = reinterpret_cast<uint4 *>(s_sum);
-    for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += MHLF_WG) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += WG) z[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x == 0) s_hmax = 0u;
   }
   __syncthreads();
@@ -506,32 +557,52 @@ __global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fuse
   const int sub = lane & (G - 1), grp = lane / G;
   uint32_t hmax = 0;                                       // largest h this lane has seen on a kept row (0xFFFFFFFF: a stray code)
 
-  // ---- accumulate: G lanes own a row, W contiguous bytes per lane; the next step's row columns are fetched early; the
-  //      u8 call counters are folded every MHLF_FOLD rows ----
+  // ---- accumulate: the next step's row columns are fetched early; the u8 call counters are folded every MHLF_FOLD rows ----
   for (int blo = td.row_lo; blo < td.row_hi; blo += MHLF_FOLD) {
     const int bhi = td.row_hi - blo > MHLF_FOLD ? blo + MHLF_FOLD : td.row_hi;
-    int64_t n_rs = 0, n_re = 0;
+    // Row columns are fetched one step ahead.  PIPE (the two-block shapes: four waves per SIMD, registers to spare): the
+    // row's BYTES are fetched a step ahead too -- the loads of step i + 1 are issued before step i is analysed, so a
+    // wavefront hides its own memory latency instead of relying on the other waves of the SIMD.
+    constexpr bool PIPE = CB > 0;
+    int64_t n_rs = 0, n_re = 0;                             // columns of the next row this lane loads bytes for
     int32_t n_st = 0, n_sd = 1;
+    auto load_cols = [&](int rr) {
+      n_rs = 0; n_re = 0; n_st = 0; n_sd = 1;
+      if (rr < bhi) { n_rs = a.off[rr]; n_re = a.off[rr + 1]; n_st = a.start[rr]; n_sd = a.strand[rr]; }
+    };
+    struct Geo { int32_t rel, len, sd; bool valid; };
+    auto geo_of = [&](int rr) { Geo g; g.rel = (int32_t)((uint32_t)n_st - (uint32_t)td.pos0); g.len = (int32_t)(n_re - n_rs); g.sd = n_sd; g.valid = rr < bhi; return g; };
+    auto load_bytes = [&](const Geo &g) {                   // (uses n_rs: call before the columns move on)
+      const int32_t lo0 = (g.rel & 15) - sub * W;
+      return g.valid ? mhlf_load<C>(a.xm, a.xm_cap, n_rs - lo0, lo0, lo0 + g.len) : ChunkRaw<C>{{0}, 0, 0};
+    };
+    Geo gq = {0, 0, 1, false};                              // PIPE: geometry of the row whose bytes are in `rawq`
+    ChunkRaw<C> rawq = {{0}, 0, 0};
     {
       const int r0 = blo + wave * R + grp;
-      if (r0 < bhi) { n_rs = a.off[r0]; n_re = a.off[r0 + 1]; n_st = a.start[r0]; n_sd = a.strand[r0]; }
+      load_cols(r0);
+      if constexpr (PIPE) { gq = geo_of(r0); rawq = load_bytes(gq); load_cols(r0 + NW * R); }
     }
     for (int rbase = blo + wave * R; rbase < bhi; rbase += NW * R) {
       const int r = rbase + grp;
-      const bool valid = r < bhi;
-      if (!EPI_DEV_CHECK(a.dbg, !valid || (r >= 0 && r < a.nrows && n_re >= n_rs && n_re - n_rs <= (int64_t)G * W), 31, r, n_re - n_rs)) return;
-      const int32_t st = n_st, sd = n_sd;
-      const int32_t rel = (int32_t)((uint32_t)st - (uint32_t)td.pos0);       // tile position of the row's byte 0
-      const int32_t len = (int32_t)(n_re - n_rs);
+      if (!EPI_DEV_CHECK(a.dbg, r >= bhi || (r >= 0 && r < a.nrows), 31, r, 0)) return;
+      Geo g;
+      ChunkRaw<C> raw;
+      if constexpr (PIPE) {
+        g = gq; raw = rawq;
+        gq = geo_of(r + NW * R);                                              // the next row: its bytes go out now,
+        rawq = load_bytes(gq);
+        load_cols(r + 2 * NW * R);                                            // and the columns of the one after
+      } else {
+        g = geo_of(r);
+        raw = load_bytes(g);
+        load_cols(r + NW * R);                                                // (in flight with the bytes)
+      }
+      const bool valid = g.valid;
+      const int32_t rel = g.rel, len = g.len, sd = g.sd;                      // tile position of the row's byte 0, its bytes, strand
+      if (!EPI_DEV_CHECK(a.dbg, !valid || (len >= 0 && len <= G * W), 32, r, len)) return;
       const int32_t P0 = rel - (rel & 15) + sub * W;                          // tile position of this lane's byte 0 (multiple of 16)
       const int32_t lo0 = (rel & 15) - sub * W, hi0 = lo0 + len;              // the row's bytes relative to the lane's byte 0
-      const int64_t g0 = n_rs - lo0;                                          // the lane's byte offset in xm
-      ChunkRaw<C> raw = valid ? mhlf_load<C>(a.xm, a.xm_cap, g0, lo0, hi0) : ChunkRaw<C>{{0}, 0, 0};
-      {
-        const int rn = r + NW * R;                                            // (in flight with the bytes)
-        n_rs = 0; n_re = 0; n_st = 0; n_sd = 1;
-        if (rn < bhi) { n_rs = a.off[rn]; n_re = a.off[rn + 1]; n_st = a.start[rn]; n_sd = a.strand[rn]; }
-      }
       if (EPI_MHLF_ABLATE & 2) {                                              // timing builds: loads only
         uint32_t x = 0;
 #pragma unroll
@@ -541,81 +612,85 @@ __global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fuse
       }
       mhlf_zero_outside<C>(raw);
       uint32_t npair[2 * C];
-      M U, N;
-      mhlf_planes<C>(raw.ww, a.k7, npair, U, N);
+      const uint32_t (&wwA)[4 * CA] = reinterpret_cast<const uint32_t (&)[4 * CA]>(raw.ww[0]);
+      uint32_t (&npA)[2 * CA] = reinterpret_cast<uint32_t (&)[2 * CA]>(npair[0]);
+      MA UA, NA;
+      mhlf_planes<CA>(wwA, a.k7, npA, UA, NA);
+      MB UB = 0, NB = 0;
+      if constexpr (CB > 0) {
+        const uint32_t (&wwB)[4 * CB] = reinterpret_cast<const uint32_t (&)[4 * CB]>(raw.ww[4 * CA]);
+        uint32_t (&npB)[2 * CB] = reinterpret_cast<uint32_t (&)[2 * CB]>(npair[2 * CA]);
+        mhlf_planes<CB>(wwB, a.k7, npB, UB, NB);
+      }
       const uint32_t cnts = mhlf_counts<C>(raw.ww, a.lut2);
-      const M L = N & ~U;
+      const MA LA = NA & ~UA;
+      const MB LB = NB & ~UB;
       // rare codes, from the bytes while the lane still holds them: skipped ('+', '-', filler between mates: common where
       // mates do not meet) and -- WIDE variant only -- the stray nibbles 9 / 3 / 4 / 8, which ARE the reference's
       // coverage slot and the slots of its three sums (:190-194).  The fast variant hands a tile with a stray code over.
-      M K = 0;
-      if (__builtin_expect(__ballot((cnts >> 16) & 1u) != 0ull, 0)) { if ((cnts >> 16) & 1u) K = mhlf_eq_plane<C>(raw.ww, 11u); }
-      M dbl = 0, s3 = 0, s4 = 0, s8 = 0;
+      MA KA = 0;
+      MB KB = 0;
+      if (__builtin_expect(__ballot((cnts >> 16) & 1u) != 0ull, 0)) {
+        if ((cnts >> 16) & 1u) {
+          KA = mhlf_eq_plane<CA>(wwA, 11u);
+          if constexpr (CB > 0) KB = mhlf_eq_plane<CB>(reinterpret_cast<const uint32_t (&)[4 * CB]>(raw.ww[4 * CA]), 11u);
+        }
+      }
+      MA dbl = 0, s3 = 0, s4 = 0, s8 = 0;
       if constexpr (WIDE) {
         if (__builtin_expect(__ballot((cnts >> 24) & 1u) != 0ull, 0)) {
-          if ((cnts >> 24) & 1u) { dbl = mhlf_eq_plane<C>(raw.ww, 9u); s3 = mhlf_eq_plane<C>(raw.ww, 3u); s4 = mhlf_eq_plane<C>(raw.ww, 4u); s8 = mhlf_eq_plane<C>(raw.ww, 8u); }
+          if ((cnts >> 24) & 1u) { dbl = mhlf_eq_plane<CA>(wwA, 9u); s3 = mhlf_eq_plane<CA>(wwA, 3u); s4 = mhlf_eq_plane<CA>(wwA, 4u); s8 = mhlf_eq_plane<CA>(wwA, 8u); }
         }
       }
 
-      // members of the open segment to the left (enter) and to the right (cont) of this lane
-      uint32_t pf, sf;
-      {
-        const uint32_t has = L ? 0x80000000u : 0u;
-        pf = has | (uint32_t)bm_popc(U & (L ? ~bm_below<M>(bm_msb(L) + 1) : ~(M)0));       // members after the last cut
-        sf = has | (uint32_t)bm_popc(U & (L ? ((L & ((M)0 - L)) - (M)1) : ~(M)0));         // members before the first cut
-      }
+      // members of the open segment to the left (enter) and to the right (cont) of each block: the lane's blocks are
+      // combined like two lanes, the lanes scanned, and the blocks' own elements applied again
+      uint32_t pfA, sfA, pfB = 0u, sfB = 0u;
+      mhlf_block_seg<MA>(UA, LA, pfA, sfA);
+      if constexpr (CB > 0) mhlf_block_seg<MB>(UB, LB, pfB, sfB);
+      uint32_t pf = CB > 0 ? mhlf_seg(pfA, pfB) : pfA, sf = CB > 0 ? mhlf_seg(sfB, sfA) : sfA;
       mhlf_seg_scan<G, 1>(pf, sf, sub);
-      uint32_t enter = grp_up<G, 1>(pf) & 0x7FFFFFFFu, cont = grp_down<G, 1>(sf) & 0x7FFFFFFFu;
-      if (sub == 0) enter = 0u;
-      if (sub == G - 1) cont = 0u;
+      uint32_t up = grp_up<G, 1>(pf), down = grp_down<G, 1>(sf);             // state of the lanes to the left / right
+      if (sub == 0) up = 0u;
+      if (sub == G - 1) down = 0u;
+      const uint32_t enterA = up & 0x7FFFFFFFu, contLast = down & 0x7FFFFFFFu;
+      const uint32_t enterB = mhlf_seg(up, pfA) & 0x7FFFFFFFu, contA = CB > 0 ? mhlf_seg(down, sfB) & 0x7FFFFFFFu : contLast;
       // row totals, two per word: h | oo_m << 16, oo_u | (lanes with skipped bytes) << 16 | (lanes with stray codes) << 24
-      const uint32_t s1 = grp_sum<G / 2>((uint32_t)bm_popc(N) | ((cnts & 255u) << 16));
+      const uint32_t s1 = grp_sum<G / 2>((uint32_t)(bm_popc(NA) + bm_popc(NB)) | ((cnts & 255u) << 16));
       const uint32_t s2 = grp_sum<G / 2>(((cnts >> 8) & 255u) | (cnts & 0x01010000u));
       const uint32_t h = s1 & 0xFFFFu, oo_m = s1 >> 16, oo_u = s2 & 0xFFFFu;
       const bool anyk = (s2 & 0x00FF0000u) != 0u, anystray = (s2 >> 24) != 0u;
       const bool keep = valid && len > 0 && !((int)h < a.hmin) && oo_m < a.keep_tab[oo_m + oo_u];   // :176-179
       if (keep) {
         const int sidx = sd - 1;
-        const unsigned long long sh = mhl_lut(h, a.H);                         // S(h), :194
-        ST *dn = s_sum + (0 + sidx) * T, *dh = s_sum + (2 + sidx) * T, *dd = s_sum + (4 + sidx) * T;
-        uint32_t *covp = WIDE ? s_cov + sidx * T : s_cov;
-        const uint32_t unit = WIDE ? 1u : (sidx ? 65536u : 1u);
+        MhlfRow<ST> c;
+        c.dn = s_sum + (0 + sidx) * T; c.dh = s_sum + (2 + sidx) * T; c.dd = s_sum + (4 + sidx) * T;
+        c.covp = WIDE ? s_cov + sidx * T : s_cov;
+        c.n8 = s_n8 + sidx * Q;
+        c.unit = WIDE ? 1u : (sidx ? 65536u : 1u);
+        c.h = h; c.H = a.H; c.anyk = anyk;
+        c.sh = mhl_lut(h, a.H);                                                // S(h), :194
         if (sub == 0) {
-          mhlf_interval(covp, rel, rel + len, unit);                           // coverage of the whole row; skipped bytes corrected below
+          mhlf_interval(c.covp, rel, rel + len, c.unit);                       // coverage of the whole row; skipped bytes corrected per block
           if (!anyk) {                                                         // every byte counted: one interval per sum (:192, :194)
-            mhlf_interval(dh, rel, rel + len, (unsigned long long)h);
-            mhlf_interval(dd, rel, rel + len, sh);
+            mhlf_interval(c.dh, rel, rel + len, (unsigned long long)h);
+            mhlf_interval(c.dd, rel, rel + len, c.sh);
           }
         }
         hmax = h > hmax ? h : hmax;
-        // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
-        const M P = (EPI_MHLF_ABLATE & 4) ? (M)0 : mhlf_span_bits<W, M>(U, L, K, enter, cont);
-        mhlf_for_runs<W, M>(P, true, U, L, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(dn, P0 + f, P0 + f + e, mhl_lut(m, a.H)); });
-        // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any
-        unsigned long long *n8 = reinterpret_cast<unsigned long long *>(s_n8 + sidx * Q + (P0 >> 2));
-#pragma unroll
-        for (int e = 0; e < 2 * C; e++) {                                      // (P0 is a multiple of 16: a pair is in or out of the tile together)
-          const uint32_t np = npair[e];
-          if (np != 0u && (uint32_t)((P0 >> 2) + 2 * e) < (uint32_t)Q && !(EPI_MHLF_ABLATE & 8))
-            atomicAdd(n8 + e, (unsigned long long)((np >> 3) & 0x01010101u) | ((unsigned long long)((np >> 7) & 0x01010101u) << 32));
-        }
-        if (__builtin_expect(anyk, 0)) {
-          // reads with skipped bytes: h and S(h) per counted run, coverage -1 over the skipped runs
-          const int vlo = lo0 < 0 ? 0 : lo0, vhi = hi0 > W ? W : hi0;              // (vhi > vlo: the lane holds a skipped byte)
-          const M V = vhi > vlo ? bm_below<M>(vhi) & ~bm_below<M>(vlo) : (M)0;     // (lanes behind the row's end: nothing)
-          mhlf_for_runs<W, M>(V & ~K, false, U, L, enter, cont, [&](int f, int e, uint32_t) {
-            mhlf_interval(dh, P0 + f, P0 + f + e, (unsigned long long)h);
-            mhlf_interval(dd, P0 + f, P0 + f + e, sh);
-          });
-          mhlf_for_runs<W, M>(K, false, U, L, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(covp, P0 + f, P0 + f + e, (unsigned long long)(0u - unit)); });
+        const int vlo = lo0 < 0 ? 0 : lo0, vhi = hi0 > W ? W : hi0;            // the row's bytes of this lane: [vlo, vhi)
+        mhlf_block<WA, 2 * CA, MA, ST>(c, UA, LA, KA, enterA, contA, P0, npA, vlo < WA ? vlo : WA, vhi < WA ? vhi : WA);
+        if constexpr (CB > 0) {
+          const uint32_t (&npB)[2 * CB] = reinterpret_cast<const uint32_t (&)[2 * CB]>(npair[2 * CA]);
+          mhlf_block<WB, 2 * CB, MB, ST>(c, UB, LB, KB, enterB, contLast, P0 + WA, npB, vlo > WA ? vlo - WA : 0, vhi > WA ? vhi - WA : 0);
         }
         if (__builtin_expect(anystray, 0)) {
           if constexpr (WIDE) {
             // nibble 9 IS the reference's coverage slot (+1 more, :191); nibbles 3 / 4 / 8 are the slots of the sums of :193 / :194 / :192
-            for (M m = dbl; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(covp, p, p + 1, unit); }
-            for (M m = s3; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dn, p, p + 1, 1ull); }
-            for (M m = s4; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dd, p, p + 1, 1ull); }
-            for (M m = s8; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(dh, p, p + 1, 1ull); }
+            for (MA m = dbl; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(c.covp, p, p + 1, c.unit); }
+            for (MA m = s3; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(c.dn, p, p + 1, 1ull); }
+            for (MA m = s4; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(c.dd, p, p + 1, 1ull); }
+            for (MA m = s8; m; m &= m - 1) { const int p = P0 + bm_ctz(m); mhlf_interval(c.dh, p, p + 1, 1ull); }
           } else {
             hmax = 0xFFFFFFFFu;                                                // the tile goes to the WIDE variant
           }
@@ -630,7 +705,7 @@ __global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fuse
         if (lane == 0) atomicMax(&s_hmax, m);
       }
     }
-    if (bhi < td.row_hi || nrows > MHLF_FOLD) { __syncthreads(); mhlf_fold<WIDE>(s_n8, s_nw); }   // (deep tiles only)
+    if (bhi < td.row_hi || nrows > MHLF_FOLD) { __syncthreads(); mhlf_fold<WIDE, WG>(s_n8, s_nw); }   // (deep tiles only)
     __syncthreads();
   }
   const bool folded = nrows > MHLF_FOLD;
@@ -645,12 +720,12 @@ __global__ __launch_bounds__(MHLF_WG, (WIDE ? 4 : EPI_MHLF_WPS)) void k_mhl_fuse
     }
   }
   if (td.slot >= 0) {                                      // shared with another rank: hand the raw arrays over
-    mhlf_dump_slab<WIDE, ST>(a, td.slot, folded, s_n8, s_nw, s_cov, s_sum);
+    mhlf_dump_slab<WIDE, ST, WG>(a, td.slot, folded, s_n8, s_nw, s_cov, s_sum);
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
   if (EPI_MHLF_ABLATE & 1) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }   // timing builds: no emit
-  mhlf_emit<WIDE, ST>(a, tile, folded, s_n8, s_nw, s_cov, s_sum, s_scan);
+  mhlf_emit<WIDE, ST, WG>(a, tile, folded, s_n8, s_nw, s_cov, s_sum, s_scan);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slabs: one workgroup per shared slot.
@@ -668,7 +743,7 @@ __global__ __launch_bounds__(MHLF_WG) void k_mhlf_emit_slab(MhlFArgs a, const in
   for (int i = threadIdx.x; i < 2 * T; i += MHLF_WG) { s_nw[i] = (uint32_t)cnt[i]; s_cov[i] = (uint32_t)cnt[2 * T + i]; }
   for (int i = threadIdx.x; i < 6 * T; i += MHLF_WG) s_sum[i] = sum[i];
   __syncthreads();
-  mhlf_emit<true, unsigned long long>(a, tile, true, nullptr, s_nw, s_cov, s_sum, s_scan);
+  mhlf_emit<true, unsigned long long, MHLF_WG>(a, tile, true, nullptr, s_nw, s_cov, s_sum, s_scan);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -690,31 +765,58 @@ static MhlLut make_mhlf_lut2(uint32_t ctx_mask) {
   return l;
 }
 
+// Lane shape of the one-pass kernel as G * 100 + CA * 10 + CB: the smallest G * 16 * (CA + CB) that holds the longest row
+// wherever it starts inside its first 16 bytes (ties: fewer lanes).  One block per lane (CB = 0: CA = 2, 3, 4, 512-thread
+// workgroups) or two (CA = 3, CB = 2: 80 bytes per lane, 256-thread workgroups).
+static int pick_mhlf_shape(int32_t max_len) {
+  if (options().mhlf_shape > 0) {                          // A/B runs (EPIHIP_MHLF_SHAPE="G,CA[,CB]"); must cover the reads
+    const int g = options().mhlf_shape / 100, ca = options().mhlf_shape / 10 % 10, cb = options().mhlf_shape % 10;
+    if ((int64_t)g * 16 * (ca + cb) >= (int64_t)max_len + 15) return options().mhlf_shape;
+  }
+  int best = 0;
+  int64_t best_cap = 0;
+  for (int g = 2; g <= 64; g <<= 1)
+    for (int k = 0; k < 4; k++) {
+      const int ca = k < 3 ? 2 + k : 3, cb = k < 3 ? 0 : 2;
+      if (cb && (g < 4 || g > 32)) continue;
+      const int64_t cap = (int64_t)g * 16 * (ca + cb);
+      if (cap < (int64_t)max_len + 15) continue;
+      if (!best || cap < best_cap) { best = g * 100 + ca * 10 + cb; best_cap = cap; }
+    }
+  return best;
+}
+
 template <bool WIDE>
-static void launch_mhl_fused(int gc, unsigned grid, int nt, hipStream_t s, const MhlFArgs &a) {
-#define EPI_LAUNCH(GG)                                                                                                 \
-  case GG * 8 + 2: hipLaunchKernelGGL((k_mhl_fused<GG, 2, WIDE>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 8 + 3: hipLaunchKernelGGL((k_mhl_fused<GG, 3, WIDE>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 8 + 4: hipLaunchKernelGGL((k_mhl_fused<GG, 4, WIDE>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, const MhlFArgs &a) {
+  const int g0 = shape / 100, ca = shape / 10 % 10, cb = shape % 10;
   if constexpr (WIDE) {
     // the WIDE variant is the rarely taken one: only the four-chunk lane shapes are built (the smallest that holds the rows)
-    int g = gc >> 3;
-    if ((gc & 7) != 4) { const int64_t cap = (int64_t)(gc >> 3) * 16 * (gc & 7); g = 2; while (g < 64 && (int64_t)g * 64 < cap) g <<= 1; }
+    const int64_t cap = (int64_t)g0 * 16 * (ca + cb);
+    int g = 2;
+    while (g < 64 && (int64_t)g * 64 < cap) g <<= 1;
     switch (g) {
-      case 2: hipLaunchKernelGGL((k_mhl_fused<2, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-      case 4: hipLaunchKernelGGL((k_mhl_fused<4, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-      case 8: hipLaunchKernelGGL((k_mhl_fused<8, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-      case 16: hipLaunchKernelGGL((k_mhl_fused<16, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-      case 32: hipLaunchKernelGGL((k_mhl_fused<32, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-      default: hipLaunchKernelGGL((k_mhl_fused<64, 4, true>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      case 2: hipLaunchKernelGGL((k_mhl_fused<2, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      case 4: hipLaunchKernelGGL((k_mhl_fused<4, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      case 8: hipLaunchKernelGGL((k_mhl_fused<8, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      case 16: hipLaunchKernelGGL((k_mhl_fused<16, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      case 32: hipLaunchKernelGGL((k_mhl_fused<32, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+      default: hipLaunchKernelGGL((k_mhl_fused<64, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
     }
   } else {
-    switch (gc) {
+#define EPI_LAUNCH(GG)                                                                                                                   \
+  case GG * 100 + 20: hipLaunchKernelGGL((k_mhl_fused<GG, 2, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
+  case GG * 100 + 30: hipLaunchKernelGGL((k_mhl_fused<GG, 3, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
+  case GG * 100 + 40: hipLaunchKernelGGL((k_mhl_fused<GG, 4, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
+#define EPI_LAUNCH2(GG) \
+  case GG * 100 + 32: hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt); break;
+    switch (shape) {
       EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
+      EPI_LAUNCH2(4) EPI_LAUNCH2(8) EPI_LAUNCH2(16) EPI_LAUNCH2(32)
       default: break;
     }
-  }
 #undef EPI_LAUNCH
+#undef EPI_LAUNCH2
+  }
 }
 
 bool mhl_fused_eligible(epi_batch *b, uint32_t ctx_mask, const RowStats &st) {
@@ -758,9 +860,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     if (nshared > 0) return fail(EPI_ERR_STATE, "shared tiles were attached for the one-pass lMHL kernel, but this batch needs the two-kernel path");
     return EPI_OK;
   }
-  int gc = pick_mhl_group(st.max_len);
-  if (options().mhlf_shape > 0 && (int64_t)(options().mhlf_shape >> 3) * 16 * (options().mhlf_shape & 7) >= (int64_t)st.max_len + 15)
-    gc = options().mhlf_shape;                             // A/B runs (EPIHIP_MHLF_SHAPE="G,C"); must cover the reads
+  const int gc = pick_mhlf_shape(st.max_len);
   uint32_t k = 0;
   for (uint32_t c : {2u, 6u, 7u}) if (ctx_mask == ((1u << c) | (1u << (c + 8)))) k = c;
   b->last_ntiles = nt;
