@@ -42,6 +42,12 @@ namespace epi {
 #ifndef EPI_MHLF_WPS
 #define EPI_MHLF_WPS 8
 #endif
+#ifndef EPI_MHLF_PIPE
+#define EPI_MHLF_PIPE 0                           // two-block shapes: byte loads one step ahead
+#endif
+#ifndef EPI_MHLF_NOFOLD
+#define EPI_MHLF_NOFOLD 0                         // timing builds: no folded call counters in the two-block fast variant (tiles over 255 rows go deep)
+#endif
 #ifndef EPI_MHLF_ABLATE
 #define EPI_MHLF_ABLATE 0                         // 1: no emit, 2: no row analysis (loads only), 4: no stretch runs, 8: no call counters
 #endif
@@ -171,14 +177,14 @@ __device__ __forceinline__ void mhlf_planes(const uint32_t (&ww)[4 * C], uint32_
                                             typename MaskOf<C>::T &U, typename MaskOf<C>::T &N) {
   using M = typename MaskOf<C>::T;
   uint32_t ulo = 0, uhi = 0, nlo = 0, nhi = 0;
+  const uint32_t k77 = k7 | (k7 << 4);
 #pragma unroll
   for (int e = 0; e < 2 * C; e++) {
-    const uint32_t wa = ww[2 * e], wb = ww[2 * e + 1];
-    const uint32_t za = ((wa ^ k7) & 0x07070707u) + 0x07070707u, zb = ((wb ^ k7) & 0x07070707u) + 0x07070707u;
-    const uint32_t nz = (za & 0x08080808u) | ((zb << 4) & 0x80808080u);
-    const uint32_t wp = (wa & 0x08080808u) | ((wb << 4) & 0x80808080u);
-    const uint32_t np = ~nz & 0x88888888u;
-    const uint32_t up = np & ~wp;
+    // the codes of the two dwords as the nibbles of one word (first dword low): one compare serves eight bytes
+    const uint32_t pk = (ww[2 * e] & 0x0F0F0F0Fu) | ((ww[2 * e + 1] << 4) & 0xF0F0F0F0u);
+    const uint32_t z = ((pk & 0x77777777u) ^ k77) + 0x77777777u;                   // bit 3 of a nibble: code NOT of the context
+    const uint32_t np = ~z & 0x88888888u;
+    const uint32_t up = np & ~pk;
     npair[e] = np;
     asm("" : "+v"(npair[e]));                              // (one register per pair: keeps the compiler from carrying both sums instead)
     // byte = 8 * flag(first dword) + 128 * flag(second): weights 1, 2, 4, 8 give (mask byte) << 3
@@ -261,19 +267,27 @@ __device__ __forceinline__ M mhlf_span_bits(M U, M L, M K, uint32_t enter, uint3
 // calls fn(first bit, length, m) for every run of set bits; for stretches m = members of the run's segment (the lanes to
 // the left / right contribute `enter` / `cont` when the segment reaches the lane's edge)
 template <int W, class M, class FN>
-__device__ __forceinline__ void mhlf_for_runs(M bits_, bool stretch, M U, M L, uint32_t enter, uint32_t cont, FN fn) {
-  uint64_t bits = (uint64_t)bits_;
-  const uint64_t nl = (uint64_t)(~L & bm_below<M>(W)), rnl = __brevll(nl);
+__device__ __forceinline__ void mhlf_for_runs(M bits_, bool stretch, M U, M L, M K, uint32_t enter, uint32_t cont, FN fn) {
+  using X = typename std::conditional<(W <= 32), uint32_t, uint64_t>::type;      // (a 32-byte block: 32-bit arithmetic)
+  X bits = (X)bits_;
   while (bits) {
-    const uint64_t low = bits & (0ull - bits);
-    const uint64_t run = ((bits + low) ^ bits) & bits;                           // the maximal run starting at `low`
-    const int f = bm_ctz(low), e = __popcll(run);
+    const X low = bits & ((X)0 - bits);
+    const X run = ((bits + low) ^ bits) & bits;                                  // the maximal run starting at `low`
+    const int f = bm_ctz(low), e = bm_popc(run);
     uint32_t m = 0;
     if (stretch) {
-      const uint64_t up = mhlf_fill_up(low, nl);
-      const uint64_t dn = __brevll(mhlf_fill_up(__brevll(low), rnl));
-      const uint64_t seg = up | dn;
-      m = ((seg & 1ull) ? enter : 0u) + (uint32_t)__popcll((uint64_t)U & seg) + (((seg >> (W - 1)) & 1ull) ? cont : 0u);
+      if (__builtin_expect(K != (M)0, 0)) {
+        // skipped bytes may split the span of a segment into several runs: the members of the whole segment
+        const uint64_t nl = (uint64_t)(~L & bm_below<M>(W)), rnl = __brevll(nl);
+        const uint64_t up = mhlf_fill_up((uint64_t)low, nl);
+        const uint64_t dn = __brevll(mhlf_fill_up(__brevll((uint64_t)low), rnl));
+        const uint64_t seg = up | dn;
+        m = ((seg & 1ull) ? enter : 0u) + (uint32_t)__popcll((uint64_t)U & seg) + (((seg >> (W - 1)) & 1ull) ? cont : 0u);
+      } else {
+        // the span of a segment is one run from its first to its last member; it reaches a lane edge iff the segment
+        // goes on there (and `enter` / `cont` is 0 when it does not)
+        m = (uint32_t)bm_popc((X)U & run) + (f == 0 ? enter : 0u) + (f + e == W ? cont : 0u);
+      }
     }
     fn(f, e, m);
     bits ^= run;
@@ -478,7 +492,7 @@ __device__ __forceinline__ void mhlf_block(const MhlfRow<ST> &c, M U, M L, M K, 
                                            const uint32_t (&np)[NPAIR], int vlo, int vhi) {
   // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
   const M P = (EPI_MHLF_ABLATE & 4) ? (M)0 : mhlf_span_bits<W, M>(U, L, K, enter, cont);
-  mhlf_for_runs<W, M>(P, true, U, L, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(c.dn, P0 + f, P0 + f + e, mhl_lut(m, c.H)); });
+  mhlf_for_runs<W, M>(P, true, U, L, K, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(c.dn, P0 + f, P0 + f + e, mhl_lut(m, c.H)); });
   // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any
   unsigned long long *n8 = reinterpret_cast<unsigned long long *>(c.n8 + (P0 >> 2));
 #pragma unroll
@@ -489,11 +503,11 @@ __device__ __forceinline__ void mhlf_block(const MhlfRow<ST> &c, M U, M L, M K, 
   if (__builtin_expect(c.anyk, 0)) {
     // reads with skipped bytes: h and S(h) per counted run, coverage -1 over the skipped runs
     const M V = vhi > vlo ? bm_below<M>(vhi) & ~bm_below<M>(vlo) : (M)0;       // (lanes behind the row's end: nothing)
-    mhlf_for_runs<W, M>(V & ~K, false, U, L, enter, cont, [&](int f, int e, uint32_t) {
+    mhlf_for_runs<W, M>(V & ~K, false, U, L, K, enter, cont, [&](int f, int e, uint32_t) {
       mhlf_interval(c.dh, P0 + f, P0 + f + e, (unsigned long long)c.h);
       mhlf_interval(c.dd, P0 + f, P0 + f + e, c.sh);
     });
-    mhlf_for_runs<W, M>(K, false, U, L, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(c.covp, P0 + f, P0 + f + e, (unsigned long long)(0u - c.unit)); });
+    mhlf_for_runs<W, M>(K, false, U, L, K, enter, cont, [&](int f, int e, uint32_t) { mhlf_interval(c.covp, P0 + f, P0 + f + e, (unsigned long long)(0u - c.unit)); });
   }
 }
 
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
   using ST = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;
   constexpr int C = CA + CB, WA = 16 * CA, WB = 16 * CB, W = 16 * C, T = MHLF_T, Q = MHLF_Q, R = 64 / G, NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t s_n8[2 * Q];                      // [strand][Q]: calls of the context, u8 x 4 positions
-  __shared__ __attribute__((aligned(16))) uint32_t s_nw[mhlf_lds_words<WIDE>()];     // the same, folded every 255 rows
+  __shared__ __attribute__((aligned(16))) uint32_t s_nw[(EPI_MHLF_NOFOLD && !WIDE && CB > 0) ? 4 : mhlf_lds_words<WIDE>()];   // the same, folded every 255 rows
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[mhlf_lds_words<WIDE>()];    // coverage difference array(s)
   __shared__ __attribute__((aligned(16))) ST s_sum[6 * T];                           // [S(M), h, S(h)][strand][T] difference arrays
   __shared__ uint32_t s_scan[NW + 2];
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
     // Row columns are fetched one step ahead.  PIPE (the two-block shapes: four waves per SIMD, registers to spare): the
     // row's BYTES are fetched a step ahead too -- the loads of step i + 1 are issued before step i is analysed, so a
     // wavefront hides its own memory latency instead of relying on the other waves of the SIMD.
-    constexpr bool PIPE = CB > 0;
+    constexpr bool PIPE = CB > 0 && EPI_MHLF_PIPE;
     int64_t n_rs = 0, n_re = 0;                             // columns of the next row this lane loads bytes for
     int32_t n_st = 0, n_sd = 1;
     auto load_cols = [&](int rr) {
@@ -905,7 +919,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   }
   a.deep_count = b->misc.as<uint32_t>() + 3;
   a.deep_list = b->heavy_list.as<uint32_t>();
-  a.max_rows = MHLF_FAST_ROWS;
+  a.max_rows = EPI_MHLF_NOFOLD ? MHLF_FOLD : MHLF_FAST_ROWS;
   if (options().heavy_rows > 0 && options().heavy_rows < MHLF_FAST_ROWS) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;

@@ -12,6 +12,7 @@ p1) run p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_
 p2) run p2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC;;
 p3) run p3 FETCH_SIZE GRBM_GUI_ACTIVE;;
 p4) run p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum;;
+p5) run p5 SQ_INST_CYCLES_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_ADDR_CONFLICT SQ_WAVES SQ_CYCLES;;
 esac
 done
 python3 - <<PY > $OUT/summary.txt
