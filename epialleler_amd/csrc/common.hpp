@@ -112,6 +112,8 @@ struct epi_batch {
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
   uint32_t mhlf_slot = 0;                      // ... and its fused kernel (1024-position tiles)
   bool mhlf_prefer_wide = false;               // most tiles of the last fused lMHL report needed the u64 sums: start with that variant
+  bool mhlf_prefer_fold = false;               // ... many held more than 255 rows: use the kernel with the folded call counters
+  epi::DevBuf mhlf_fold_slab;                  // call counters of tiles over 255 rows (kernels built without the LDS fold array)
   bool mhl_shared_fused = false;               // the lMHL slabs attached are in the fused kernel's layout (mhl_common.hpp)
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes

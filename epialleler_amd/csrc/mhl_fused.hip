@@ -45,15 +45,13 @@ namespace epi {
 #ifndef EPI_MHLF_PIPE
 #define EPI_MHLF_PIPE 0                           // two-block shapes: byte loads one step ahead
 #endif
-#ifndef EPI_MHLF_NOFOLD
-#define EPI_MHLF_NOFOLD 0                         // timing builds: no folded call counters in the two-block fast variant (tiles over 255 rows go deep)
-#endif
 #ifndef EPI_MHLF_ABLATE
 #define EPI_MHLF_ABLATE 0                         // 1: no emit, 2: no row analysis (loads only), 4: no stretch runs, 8: no call counters
 #endif
 constexpr int MHLF_WG = EPI_MHLF_WG, MHLF_NW = MHLF_WG / 64, MHLF_Q = MHLF_T / 4;
 constexpr int MHLF_WG2 = 256;                     // workgroup of the two-block lane shapes
 constexpr int MHLF_FOLD = 255;                    // u8 call counters: a row adds at most 1 per position
+constexpr uint32_t MHLF_FOLD_SLOTS = 2048;        // slab slots (8 KB each) of the kernels built without the LDS fold array
 constexpr int MHLF_FAST_ROWS = 32767;             // packed u16 coverage halves / u16 folded counters of the fast variant
 
 // mhl_keep's out-of-context test without the fp64 division per row: (double)m / (double)n > max_oo is monotone in m, so
@@ -90,6 +88,8 @@ struct MhlFArgs {
   uint32_t *deep_count, *deep_list;       // tiles the fast variant sets aside for the WIDE one
   const uint32_t *tile_list;              // non-null: the launch covers tile_list[0 .. ntiles) (the deep list)
   int max_rows;                           // fast variant: tiles with more candidate rows go to the deep list
+  uint32_t *fold_slab, *fold_cursor;      // kernels built without the LDS fold array: u32 [slot][2][T] call counters of the
+  uint32_t fold_slots;                    // tiles with more than 255 rows, slots handed out through the cursor
   int32_t *slab_cnt;                      // shared tiles: [slot][MHLF_CNT_PLANES][T] int32, [slot][MHLF_SUM_PLANES][T] int64
   unsigned long long *slab_sum;
   uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
@@ -134,6 +134,28 @@ __device__ __forceinline__ ChunkRaw<C> mhlf_load(const uint8_t *__restrict__ xm,
         r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
       }
     }
+  }
+  return r;
+}
+
+// The same through a raw buffer descriptor over [base, base + num_records) whose offsets are 32 bits wide: a chunk the row
+// does not reach is sent to an offset past num_records, which the hardware answers with zeros -- no registers to clear and
+// no branches, one compare and one select per chunk.  For lanes whose W bytes lie inside the descriptor (the caller sends a
+// wavefront with any other lane through mhlf_load).
+typedef uint32_t MhlfU4 __attribute__((ext_vector_type(4)));
+template <int C>
+__device__ __forceinline__ ChunkRaw<C> mhlf_load_buf(__amdgpu_buffer_rsrc_t rs, int32_t g32, int32_t lo0, int32_t hi0, bool valid) {
+  constexpr int W = 16 * C;
+  ChunkRaw<C> r;
+  const int32_t lo = lo0 < 0 ? 0 : lo0, hi = hi0 > W ? W : hi0;
+  const bool any = valid && hi > lo;
+  r.lo = any ? lo : 0; r.hi = any ? hi : 0;
+  const int32_t hiv = any ? hi0 : 0;
+#pragma unroll
+  for (int j = 0; j < C; j++) {
+    const int32_t vo = 16 * j < hiv ? g32 : (int32_t)0x80000000u;
+    const MhlfU4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * j, 0, 0);   // (16 j: the instruction's offset field)
+    r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
   }
   return r;
 }
@@ -364,7 +386,7 @@ __device__ __forceinline__ void mhlf_scan_array(X *arr, int lane) {
 // Prefix sums of the difference arrays, the rule (a row iff n > cov/2), ordered rows into the tile's pool slot.
 //  fast layout: s_cov u32 [T] ('+' in the low half, '-' in the high), calls in s_n8 (u8) or, folded, s_nw (u16 pairs)
 //  WIDE layout: s_cov u32 [2][T], calls in s_n8 or, folded, s_nw u32 [2][T]
-template <bool WIDE, class ST, int WG>
+template <bool WIDE, class ST, int WG, bool NW32 = WIDE>
 __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool folded, const uint32_t *s_n8, const uint32_t *s_nw,
                                           uint32_t *s_cov, ST *s_sum, uint32_t *s_scan) {
   constexpr int T = MHLF_T, Q = MHLF_Q, NW = WG / 64, PPT = T / WG;
@@ -393,7 +415,7 @@ __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool fold
       const int p = p0 + j;
       uint32_t n, c;
       if (!folded) n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
-      else if constexpr (WIDE) n = s_nw[s * T + p];
+      else if constexpr (NW32) n = s_nw[s * T + p];
       else n = (s_nw[s * (T / 2) + (p >> 1)] >> (16 * (p & 1))) & 0xFFFFu;
       if constexpr (WIDE) c = s_cov[s * T + p];
       else { const uint32_t v = s_cov[p]; c = s ? v >> 16 : v & 0xFFFFu; }
@@ -444,7 +466,7 @@ __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool fold
 }
 
 // raw arrays of a tile that other ranks contribute to -> its slot of the slabs (summed across ranks by the caller)
-template <bool WIDE, class ST, int WG>
+template <bool WIDE, class ST, int WG, bool NW32 = WIDE>
 __device__ __forceinline__ void mhlf_dump_slab(const MhlFArgs &a, int slot, bool folded, const uint32_t *s_n8, const uint32_t *s_nw,
                                                const uint32_t *s_cov, const ST *s_sum) {
   constexpr int T = MHLF_T, Q = MHLF_Q;
@@ -454,7 +476,7 @@ __device__ __forceinline__ void mhlf_dump_slab(const MhlFArgs &a, int slot, bool
     const int s = i / T, p = i % T;
     uint32_t n;
     if (!folded) n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
-    else if constexpr (WIDE) n = s_nw[s * T + p];
+    else if constexpr (NW32) n = s_nw[s * T + p];
     else n = (s_nw[s * (T / 2) + (p >> 1)] >> (16 * (p & 1))) & 0xFFFFu;
     if (n) atomicAdd(cnt + s * T + p, (int32_t)n);
     int32_t d;
@@ -519,21 +541,25 @@ __device__ __forceinline__ void mhlf_block_seg(M U, M L, uint32_t &pf, uint32_t 
   sf = has | (uint32_t)bm_popc(U & (L ? ((L & ((M)0 - L)) - (M)1) : ~(M)0));
 }
 
-template <bool WIDE, int WG> constexpr int mhlf_wps() { return WIDE ? (WG >= 512 ? 4 : 2) : (WG >= 512 ? EPI_MHLF_WPS : 4); }
+template <bool WIDE, int WG, bool FOLD> constexpr int mhlf_wps() {      // waves per SIMD the register allocation aims at
+  return WIDE ? (WG >= 512 ? 4 : 2) : (WG >= 512 ? EPI_MHLF_WPS : (FOLD ? 4 : 5));      // (what the LDS of a workgroup allows)
+}
 
 // G lanes own a row.  A lane holds 16 * (CA + CB) contiguous bytes as one or two mask blocks: CB = 0 is one block of up to
 // 64 bytes (64-bit masks); CA = 3, CB = 2 is 80 bytes as a 48-byte and a 32-byte block, each with masks of its own, the
 // two combined like two lanes before the lane scans -- 4 lanes x 80 bytes hold a PE150 template (16 rows per wavefront
 // step where 8 lanes x 48 bytes hold 8: the work that is per lane, not per byte, halves per row).
-template <int G, int CA, int CB, bool WIDE, int WG>
-__global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFArgs a, int ntiles) {
+template <int G, int CA, int CB, bool WIDE, int WG, bool FOLD = true>
+__global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(MhlFArgs a, int ntiles) {
+  static_assert(FOLD || !WIDE, "only the fast variant is built without the folded counters");
   static_assert(!(WIDE && CB), "the WIDE variant is built with one block per lane");
   using MA = typename MaskOf<CA>::T;
   using MB = uint32_t;                                     // CB <= 2
   using ST = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;
   constexpr int C = CA + CB, WA = 16 * CA, WB = 16 * CB, W = 16 * C, T = MHLF_T, Q = MHLF_Q, R = 64 / G, NW = WG / 64;
   __shared__ __attribute__((aligned(16))) uint32_t s_n8[2 * Q];                      // [strand][Q]: calls of the context, u8 x 4 positions
-  __shared__ __attribute__((aligned(16))) uint32_t s_nw[(EPI_MHLF_NOFOLD && !WIDE && CB > 0) ? 4 : mhlf_lds_words<WIDE>()];   // the same, folded every 255 rows
+  __shared__ __attribute__((aligned(16))) uint32_t s_nw[FOLD ? mhlf_lds_words<WIDE>() : 4];   // the same, folded every 255 rows.  !FOLD:
+  // 4 KB less LDS (a fifth workgroup per CU); the rare tile with more than 255 rows folds into a slot of a slab in HBM
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[mhlf_lds_words<WIDE>()];    // coverage difference array(s)
   __shared__ __attribute__((aligned(16))) ST s_sum[6 * T];                           // [S(M), h, S(h)][strand][T] difference arrays
   __shared__ uint32_t s_scan[NW + 2];
@@ -553,12 +579,29 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
     if (threadIdx.x == 0) { a.deep_list[atomicAdd(a.deep_count, 1u)] = (uint32_t)tile; a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
+  uint32_t *nw = s_nw;                                     // folded call counters (LDS, or the tile's slot of the slab)
+  if constexpr (!FOLD) {
+    if (nrows > MHLF_FOLD) {
+      if (threadIdx.x == 0) s_scan[0] = atomicAdd(a.fold_cursor, 1u);
+      __syncthreads();
+      const uint32_t fs = s_scan[0];
+      if (fs >= a.fold_slots) {                            // (no slot left: the WIDE variant takes the tile)
+        if (threadIdx.x == 0) { a.deep_list[atomicAdd(a.deep_count, 1u)] = (uint32_t)tile; a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+        return;
+      }
+      nw = a.fold_slab + (size_t)fs * (2 * T);
+      uint4 *z = reinterpret_cast<uint4 *>(nw);            // (thread i zeroes the words it folds into: same index map as mhlf_fold)
+      for (int i = threadIdx.x; i < 2 * T / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
   {
     uint4 *z = reinterpret_cast<uint4 *>(s_n8);
     for (int i = threadIdx.x; i < 2 * Q / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
-    if (nrows > MHLF_FOLD) {
-      z = reinterpret_cast<uint4 *>(s_nw);
-      for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+    if constexpr (FOLD) {
+      if (nrows > MHLF_FOLD) {
+        z = reinterpret_cast<uint4 *>(s_nw);
+        for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+      }
     }
     z = reinterpret_cast<uint4 *>(s_cov);
     for (int i = threadIdx.x; i < mhlf_lds_words<WIDE>() / 4; i += WG) z[i] = make_uint4(0, 0, 0, 0);
@@ -569,6 +612,14 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
+  // the tile's rows through a buffer descriptor that starts 16 .. 31 bytes before the first of them (row offsets increase
+  // with the row index); a tile whose rows span 2 GB or more -- millions of rows on one kilobase -- stays with 64-bit addresses
+  const int64_t xm_lo = a.off[td.row_lo], xm_hi = a.off[td.row_hi];
+  const int64_t buf_base = (xm_lo & ~(int64_t)15) >= 16 ? (xm_lo & ~(int64_t)15) - 16 : 0;
+  const bool use_buf = xm_hi - buf_base < 0x7FFF0000ll;
+  const int64_t buf_left = a.xm_cap - buf_base;
+  const int32_t buf_n = buf_left < 0x7FFFFF00ll ? (int32_t)buf_left : 0x7FFFFF00;
+  const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.xm) + buf_base, (short)0, buf_n, 0x00020000);
   uint32_t hmax = 0;                                       // largest h this lane has seen on a kept row (0xFFFFFFFF: a stray code)
 
   // ---- accumulate: the next step's row columns are fetched early; the u8 call counters are folded every MHLF_FOLD rows ----
@@ -588,6 +639,10 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
     auto geo_of = [&](int rr) { Geo g; g.rel = (int32_t)((uint32_t)n_st - (uint32_t)td.pos0); g.len = (int32_t)(n_re - n_rs); g.sd = n_sd; g.valid = rr < bhi; return g; };
     auto load_bytes = [&](const Geo &g) {                   // (uses n_rs: call before the columns move on)
       const int32_t lo0 = (g.rel & 15) - sub * W;
+      const int32_t g32 = (int32_t)((uint32_t)n_rs - (uint32_t)buf_base) - lo0;     // the lane's byte 0 in the descriptor
+      // (a lane whose bytes reach outside the batch's buffer -- first and last rows only -- takes the wavefront along)
+      const bool out = g.valid && (g32 < 0 || g32 > buf_n - W);
+      if (__builtin_expect(use_buf && __ballot(out) == 0ull, 1)) return mhlf_load_buf<C>(buf, g32, lo0, lo0 + g.len, g.valid);
       return g.valid ? mhlf_load<C>(a.xm, a.xm_cap, n_rs - lo0, lo0, lo0 + g.len) : ChunkRaw<C>{{0}, 0, 0};
     };
     Geo gq = {0, 0, 1, false};                              // PIPE: geometry of the row whose bytes are in `rawq`
@@ -719,7 +774,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
         if (lane == 0) atomicMax(&s_hmax, m);
       }
     }
-    if (bhi < td.row_hi || nrows > MHLF_FOLD) { __syncthreads(); mhlf_fold<WIDE, WG>(s_n8, s_nw); }   // (deep tiles only)
+    if (bhi < td.row_hi || nrows > MHLF_FOLD) { __syncthreads(); mhlf_fold<WIDE || !FOLD, WG>(s_n8, nw); }   // (deep tiles only)
     __syncthreads();
   }
   const bool folded = nrows > MHLF_FOLD;
@@ -734,12 +789,12 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG>())) void k_mhl_fused(MhlFAr
     }
   }
   if (td.slot >= 0) {                                      // shared with another rank: hand the raw arrays over
-    mhlf_dump_slab<WIDE, ST, WG>(a, td.slot, folded, s_n8, s_nw, s_cov, s_sum);
+    mhlf_dump_slab<WIDE, ST, WG, WIDE || !FOLD>(a, td.slot, folded, s_n8, nw, s_cov, s_sum);
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
   if (EPI_MHLF_ABLATE & 1) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }   // timing builds: no emit
-  mhlf_emit<WIDE, ST, WG>(a, tile, folded, s_n8, s_nw, s_cov, s_sum, s_scan);
+  mhlf_emit<WIDE, ST, WG, WIDE || !FOLD>(a, tile, folded, s_n8, nw, s_cov, s_sum, s_scan);
 }
 
 // Emits the shared tiles this rank owns from the (already cross-rank reduced) slabs: one workgroup per shared slot.
@@ -801,7 +856,7 @@ static int pick_mhlf_shape(int32_t max_len) {
 }
 
 template <bool WIDE>
-static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, const MhlFArgs &a) {
+static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, const MhlFArgs &a, bool fold = true) {
   const int g0 = shape / 100, ca = shape / 10 % 10, cb = shape % 10;
   if constexpr (WIDE) {
     // the WIDE variant is the rarely taken one: only the four-chunk lane shapes are built (the smallest that holds the rows)
@@ -821,8 +876,11 @@ static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, co
   case GG * 100 + 20: hipLaunchKernelGGL((k_mhl_fused<GG, 2, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
   case GG * 100 + 30: hipLaunchKernelGGL((k_mhl_fused<GG, 3, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
   case GG * 100 + 40: hipLaunchKernelGGL((k_mhl_fused<GG, 4, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-#define EPI_LAUNCH2(GG) \
-  case GG * 100 + 32: hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt); break;
+#define EPI_LAUNCH2(GG)                                                                                                                  \
+  case GG * 100 + 32:                                                                                                                    \
+    if (fold) hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2, true>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);             \
+    else hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2, false>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);                 \
+    break;
     switch (shape) {
       EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
       EPI_LAUNCH2(4) EPI_LAUNCH2(8) EPI_LAUNCH2(16) EPI_LAUNCH2(32)
@@ -899,7 +957,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     slot = 0;
     ovf_base = 0;
   }
-  MhlFArgs a;
+  MhlFArgs a{};
   memset(&a, 0, sizeof(a));
   a.xm = b->xm; a.off = b->off; a.start = b->start; a.strand = b->strand;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;
@@ -919,8 +977,19 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   }
   a.deep_count = b->misc.as<uint32_t>() + 3;
   a.deep_list = b->heavy_list.as<uint32_t>();
-  a.max_rows = EPI_MHLF_NOFOLD ? MHLF_FOLD : MHLF_FAST_ROWS;
-  if (options().heavy_rows > 0 && options().heavy_rows < MHLF_FAST_ROWS) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
+  // Two-block shapes come with and without the LDS array of folded call counters.  Without it a workgroup needs 4 KB less
+  // LDS (five per CU instead of four) and a tile of more than 255 rows folds its u8 counters into a slot of a slab in HBM
+  // (MHLF_FOLD_SLOTS of them; a tile that finds none left goes to the WIDE variant with the other deep tiles).  Batches whose
+  // tiles average well below 255 rows start there; one that runs out of slots switches the batch over.
+  const bool fold = (gc % 10 == 0) || b->mhlf_prefer_fold || (double)b->n > 150.0 * (double)nt;
+  a.max_rows = MHLF_FAST_ROWS;
+  a.fold_slab = nullptr; a.fold_cursor = b->misc.as<uint32_t>() + 5; a.fold_slots = 0;
+  if (!fold) {
+    EPI_TRY(b->mhlf_fold_slab.ensure((size_t)MHLF_FOLD_SLOTS * 2 * T * 4));
+    a.fold_slab = b->mhlf_fold_slab.as<uint32_t>();
+    a.fold_slots = MHLF_FOLD_SLOTS;
+  }
+  if (options().heavy_rows > 0 && options().heavy_rows < a.max_rows) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   a.slot_rows = slot;
   a.ovf_base = (uint32_t)ovf_base;
   b->mhl_last_slot = slot;
@@ -938,7 +1007,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   for (int attempt = 0; attempt < 2; attempt++) {
     fill_args_common(b, a);
     if (attempt > 0) {
-      EPI_HIP(hipMemsetAsync(cursor, 0, 12, s));
+      EPI_HIP(hipMemsetAsync(cursor, 0, 20, s));           // misc[1..5]
       if (nshared > 0) {                                   // the rerun adds into the slabs again
         EPI_HIP(hipMemsetAsync(a.slab_cnt, 0, (size_t)nshared * MHLF_CNT_PLANES * T * 4, s));
         EPI_HIP(hipMemsetAsync(a.slab_sum, 0, (size_t)nshared * MHLF_SUM_PLANES * T * 8, s));
@@ -947,12 +1016,12 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     a.tile_list = nullptr;
     const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
     prof_begin("mhl_tiles", s);
-    if (b->mhlf_prefer_wide) launch_mhl_fused<true>(gc, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a);
+    if (b->mhlf_prefer_wide) launch_mhl_fused<true>(gc, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a, fold);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
-    uint32_t host4[4];
-    EPI_TRY(read_scalars(b, s, cursor - 1, 16, host4));    // {tile count, overflow rows handed out, total rows, deep tiles}
+    uint32_t host4[6];
+    EPI_TRY(read_scalars(b, s, cursor - 1, 24, host4));    // {tile count, overflow rows handed out, total rows, deep tiles, -, fold slots asked for}
     if (nt_hinted && host4[0] != (uint32_t)nt) {
       for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
       return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host4[0], nt);
@@ -970,6 +1039,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
       host4[1] = again[0]; host4[2] = again[1];
       b->mhlf_prefer_wide = host4[3] > (uint32_t)nt / 2;   // most tiles needed the wide sums: start there next time
     }
+    if (!fold && host4[5] > MHLF_FOLD_SLOTS / 2) b->mhlf_prefer_fold = true;   // many tiles over 255 rows: LDS fold array next time
     host[0] = host4[1]; host[1] = host4[2]; host[2] = host4[3];
 #ifdef EPI_CHECK
     {
@@ -997,7 +1067,7 @@ int mhl_fused_finish_shared(epi_batch *b, hipStream_t s, int64_t *nrow_out) {
   const int32_t nt = b->last_ntiles;
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
   if (nt > 0 && !b->shared_keys.empty()) {
-    MhlFArgs a;
+    MhlFArgs a{};
     memset(&a, 0, sizeof(a));
     fill_args_common(b, a);
     for (uint32_t c : {2u, 6u, 7u}) if (b->mhl_ctx_mask == ((1u << c) | (1u << (c + 8)))) a.ctx = c;

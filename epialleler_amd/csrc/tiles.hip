@@ -118,6 +118,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
   if (FILL && blockIdx.x == 0 && threadIdx.x == 0) {       // the report kernels' counters start at zero (saves three memsets)
     misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[8] = 0;    // pool cursor, output rows, heavy tiles, largest heavy tile
     misc[4] = 0;                                           // tiles the lean CX kernel hands to the general one
+    misc[5] = 0;                                           // slab slots the one-pass lMHL kernel has handed out
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t x0 = (int64_t)blockIdx.x * TB_ROWS + (int64_t)threadIdx.x * TB_ITEMS;
