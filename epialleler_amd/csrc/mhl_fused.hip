@@ -51,6 +51,7 @@ namespace epi {
 constexpr int MHLF_WG = EPI_MHLF_WG, MHLF_NW = MHLF_WG / 64, MHLF_Q = MHLF_T / 4;
 constexpr int MHLF_WG2 = 256;                     // workgroup of the two-block lane shapes
 constexpr int MHLF_FOLD = 255;                    // u8 call counters: a row adds at most 1 per position
+constexpr int MHLF_STAB = 256;                    // S(k) table entries in LDS
 constexpr uint32_t MHLF_FOLD_SLOTS = 2048;        // slab slots (8 KB each) of the kernels built without the LDS fold array
 constexpr int MHLF_FAST_ROWS = 32767;             // packed u16 coverage halves / u16 folded counters of the fast variant
 
@@ -220,11 +221,14 @@ __device__ __forceinline__ void mhlf_planes(const uint32_t (&ww)[4 * C], uint32_
   if constexpr (sizeof(M) == 8) { U |= (M)uhi << 32; N |= (M)nhi << 32; }
 }
 
-// 16-entry byte LUT lookup of the four codes of a dword
+// 16-entry byte LUT lookup of the four codes of a dword in two v_perm_b32.  A selector byte of 0 .. 7 picks a byte of the
+// two table words; 8 .. 11 give the sign of table byte 1 / 3 / 5 / 7 in all eight bits, 12 gives 0x00 and 13 .. 15 give
+// 0xFF.  So perm(low half, code) is right for codes 0 .. 7 and a constant per code for 8 .. 15, perm(high half, code ^ 8)
+// the other way round, and with the halves stored as make_mhlf_lut2 stores them (complemented where the other lookup
+// answers 0xFF) the XOR of the two is the entry.
 __device__ __forceinline__ uint32_t mhlf_lut4(uint32_t w, const MhlLut &F) {
-  const uint32_t lo3 = w & 0x07070707u;
-  const uint32_t pick = ((w >> 1) & 0x04040404u) | 0x03020100u;
-  return __builtin_amdgcn_perm(__builtin_amdgcn_perm(F.hi1, F.hi0, lo3), __builtin_amdgcn_perm(F.lo1, F.lo0, lo3), pick);
+  const uint32_t sel = w & 0x0F0F0F0Fu;
+  return __builtin_amdgcn_perm(F.lo1, F.lo0, sel) ^ __builtin_amdgcn_perm(F.hi1, F.hi0, sel ^ 0x08080808u);
 }
 
 // Out-of-context counts of the lane and its rare-code flags: the LUT byte's bits 0, 2, 4, 6 are 2-bit fields (three
@@ -314,6 +318,13 @@ __device__ __forceinline__ void mhlf_for_runs(M bits_, bool stretch, M U, M L, M
     fn(f, e, m);
     bits ^= run;
   }
+}
+
+// S(min(m, H)) (mhl_lookup[m], :110-116): from the workgroup's table while every lane's index is below MHLF_STAB
+__device__ __forceinline__ unsigned long long mhlf_S(uint32_t m, uint32_t H, const uint32_t *tab) {
+  const uint32_t k = m < H ? m : H;
+  if (__builtin_expect(__ballot(k >= (uint32_t)MHLF_STAB) != 0ull, 0)) return mhl_lut(m, H);
+  return tab[k];
 }
 
 // +v on tile positions [a, b) of one difference array of MHLF_T entries
@@ -503,6 +514,7 @@ template <bool WIDE> constexpr int mhlf_lds_words() { return WIDE ? 2 * MHLF_T :
 // the methylated stretches, the call counters of its pairs of dwords and -- rows with skipped bytes -- h and S(h) per
 // counted run and the coverage correction.
 template <class ST> struct MhlfRow {
+  const uint32_t *tab;                    // S(k) for k < MHLF_STAB
   ST *dn, *dh, *dd;                       // difference arrays of S(M), h, S(h) of the row's strand
   uint32_t *covp, *n8;                    // coverage array (of the strand, WIDE) and u8 call counters of the strand
   uint32_t unit, h, H;
@@ -514,7 +526,7 @@ __device__ __forceinline__ void mhlf_block(const MhlfRow<ST> &c, M U, M L, M K, 
                                            const uint32_t (&np)[NPAIR], int vlo, int vhi) {
   // stretches: S(M) on every counted byte between the first and the last member (:168-171, :193)
   const M P = (EPI_MHLF_ABLATE & 4) ? (M)0 : mhlf_span_bits<W, M>(U, L, K, enter, cont);
-  mhlf_for_runs<W, M>(P, true, U, L, K, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(c.dn, P0 + f, P0 + f + e, mhl_lut(m, c.H)); });
+  mhlf_for_runs<W, M>(P, true, U, L, K, enter, cont, [&](int f, int e, uint32_t m) { mhlf_interval(c.dn, P0 + f, P0 + f + e, mhlf_S(m, c.H, c.tab)); });
   // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any
   unsigned long long *n8 = reinterpret_cast<unsigned long long *>(c.n8 + (P0 >> 2));
 #pragma unroll
@@ -563,6 +575,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[mhlf_lds_words<WIDE>()];    // coverage difference array(s)
   __shared__ __attribute__((aligned(16))) ST s_sum[6 * T];                           // [S(M), h, S(h)][strand][T] difference arrays
   __shared__ uint32_t s_scan[NW + 2];
+  __shared__ uint32_t s_tab[MHLF_STAB];                                              // S(k), k < MHLF_STAB (:110-116)
   __shared__ uint32_t s_hmax;                                                        // largest h among the kept rows; 0xFFFFFFFF: a stray code
   int tile;
   if (a.tile_list) {
@@ -608,6 +621,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
     z = reinterpret_cast<uint4 *>(s_sum);
     for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += WG) z[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x == 0) s_hmax = 0u;
+    if (threadIdx.x < MHLF_STAB) s_tab[threadIdx.x] = (uint32_t)nrS(threadIdx.x);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
         c.covp = WIDE ? s_cov + sidx * T : s_cov;
         c.n8 = s_n8 + sidx * Q;
         c.unit = WIDE ? 1u : (sidx ? 65536u : 1u);
-        c.h = h; c.H = a.H; c.anyk = anyk;
+        c.h = h; c.H = a.H; c.anyk = anyk; c.tab = s_tab;
         c.sh = mhl_lut(h, a.H);                                                // S(h), :194
         if (sub == 0) {
           mhlf_interval(c.covp, rel, rel + len, c.unit);                       // coverage of the whole row; skipped bytes corrected per block
@@ -827,6 +841,9 @@ static MhlLut make_mhlf_lut2(uint32_t ctx_mask) {
     if (!in && ((0xE400u >> code) & 1u)) f |= 16u;           // codes 10, 13, 14, 15: unmethylated
     if (code == 11) f |= 4u;                                 // skipped (:187)
     if (code == 3 || code == 4 || code == 8 || code == 9) f |= 64u;   // their counters are sums / the coverage slot (:190-194)
+    // (entries are below 128.  Stored complemented, an entry's sign bit is set, which is what the other half's lookup
+    // returns -- as 0xFF -- for selectors 8 .. 11 and 13 .. 15; selector 12, i.e. codes 4 and 12, returns 0x00)
+    if ((code & 7u) != 4u) f ^= 0xFFu;
     w[code >> 2] |= f << (8 * (code & 3));
   }
   MhlLut l;
@@ -872,21 +889,20 @@ static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, co
       default: hipLaunchKernelGGL((k_mhl_fused<64, 4, 0, true, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
     }
   } else {
-#define EPI_LAUNCH(GG)                                                                                                                   \
-  case GG * 100 + 20: hipLaunchKernelGGL((k_mhl_fused<GG, 2, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 100 + 30: hipLaunchKernelGGL((k_mhl_fused<GG, 3, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;     \
-  case GG * 100 + 40: hipLaunchKernelGGL((k_mhl_fused<GG, 4, 0, false, MHLF_WG>), dim3(grid), dim3(MHLF_WG), 0, s, a, nt); break;
-#define EPI_LAUNCH2(GG)                                                                                                                  \
-  case GG * 100 + 32:                                                                                                                    \
-    if (fold) hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2, true>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);             \
-    else hipLaunchKernelGGL((k_mhl_fused<GG, 3, 2, false, MHLF_WG2, false>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);                 \
+#define EPI_LAUNCH1(GG, CCA, CCB)                                                                                                        \
+  case GG * 100 + CCA * 10 + CCB:                                                                                                        \
+    if (fold) hipLaunchKernelGGL((k_mhl_fused<GG, CCA, CCB, false, MHLF_WG2, true>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);         \
+    else hipLaunchKernelGGL((k_mhl_fused<GG, CCA, CCB, false, MHLF_WG2, false>), dim3(grid), dim3(MHLF_WG2), 0, s, a, nt);             \
     break;
+#define EPI_LAUNCH(GG) EPI_LAUNCH1(GG, 2, 0) EPI_LAUNCH1(GG, 3, 0) EPI_LAUNCH1(GG, 4, 0)
+#define EPI_LAUNCH2(GG) EPI_LAUNCH1(GG, 3, 2)
     switch (shape) {
       EPI_LAUNCH(2) EPI_LAUNCH(4) EPI_LAUNCH(8) EPI_LAUNCH(16) EPI_LAUNCH(32) EPI_LAUNCH(64)
       EPI_LAUNCH2(4) EPI_LAUNCH2(8) EPI_LAUNCH2(16) EPI_LAUNCH2(32)
       default: break;
     }
 #undef EPI_LAUNCH
+#undef EPI_LAUNCH1
 #undef EPI_LAUNCH2
   }
 }
@@ -977,11 +993,11 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   }
   a.deep_count = b->misc.as<uint32_t>() + 3;
   a.deep_list = b->heavy_list.as<uint32_t>();
-  // Two-block shapes come with and without the LDS array of folded call counters.  Without it a workgroup needs 4 KB less
+  // The fast variant comes with and without the LDS array of folded call counters.  Without it a workgroup needs 4 KB less
   // LDS (five per CU instead of four) and a tile of more than 255 rows folds its u8 counters into a slot of a slab in HBM
   // (MHLF_FOLD_SLOTS of them; a tile that finds none left goes to the WIDE variant with the other deep tiles).  Batches whose
   // tiles average well below 255 rows start there; one that runs out of slots switches the batch over.
-  const bool fold = (gc % 10 == 0) || b->mhlf_prefer_fold || (double)b->n > 150.0 * (double)nt;
+  const bool fold = b->mhlf_prefer_fold || (double)b->n > 150.0 * (double)nt;
   a.max_rows = MHLF_FAST_ROWS;
   a.fold_slab = nullptr; a.fold_cursor = b->misc.as<uint32_t>() + 5; a.fold_slots = 0;
   if (!fold) {
