@@ -55,6 +55,27 @@ struct ProfEntry { double ms = 0; int64_t n = 0; };
 
 // ---- per-read class counting shared by the per-read kernels and the fused CX tile kernel (per_read.hip) ----------
 struct ClassLut { uint32_t lo0, lo1, hi0, hi1; };   // one byte per code: codes 0-3, 4-7, 8-11, 12-15
+
+// The same table in the form two v_perm_b32 look up (lut16x in tile_common.hpp).  With a selector byte s, v_perm_b32 returns
+// byte s of its eight source bytes for s < 8, the sign of source byte 1 / 3 / 5 / 7 spread over the byte for s = 8 .. 11,
+// 0x00 for s = 12 and 0xFF for s >= 13.  So perm(low half, code) is the entry for codes 0 .. 7 and a constant per code
+// for 8 .. 15, perm(high half, code ^ 8) the other way round; the halves are stored XOR-ed with the constant the other
+// lookup returns, and the XOR of the two lookups is the entry for every code.
+inline ClassLut lut16_xor_form(const ClassLut &d) {
+  uint8_t D[16], L[8], H[8];
+  const uint32_t w[4] = {d.lo0, d.lo1, d.hi0, d.hi1};
+  for (int c = 0; c < 16; c++) D[c] = (uint8_t)(w[c >> 2] >> (8 * (c & 3)));
+  auto S = [](uint8_t x) { return (uint8_t)((x & 0x80u) ? 0xFFu : 0x00u); };
+  L[4] = D[4]; H[4] = D[12];
+  for (int j = 5; j < 8; j++) { L[j] = (uint8_t)~D[j]; H[j] = (uint8_t)~D[8 + j]; }
+  L[2] = D[2] ^ S(H[5]); L[3] = D[3] ^ S(H[7]); H[2] = D[10] ^ S(L[5]); H[3] = D[11] ^ S(L[7]);
+  L[1] = D[1] ^ S(H[3]); H[1] = D[9] ^ S(L[3]);
+  L[0] = D[0] ^ S(H[1]); H[0] = D[8] ^ S(L[1]);
+  auto pack = [](const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); };
+  ClassLut x;
+  x.lo0 = pack(L); x.lo1 = pack(L + 4); x.hi0 = pack(H); x.hi1 = pack(H + 4);
+  return x;
+}
 struct ThrParams {                                   // rcpp_threshold_reads.cpp:15-23
   uint32_t min_n_ctx;
   double min_ctx_meth_frac, max_ooctx_meth_frac;

@@ -77,6 +77,7 @@ struct Cx2Args {
   uint32_t fill4;                         // 4 x a code without any flag in either LUT (stands in for bytes outside a row)
   ClassLut lut_r;                         // report LUT: byte = [n0 M0 n1 M1 n2 M2 skip dbl] flags of a code (n: a call of
                                           // plane p's context in either case, M: a methylated one)
+  ClassLut lut_rx, lut_sx;                // ... and both in the two-lookup form the kernels read (lut16_xor_form)
   ClassLut lut_s;                         // fused: bits 0,2,4,6 = in context / methylated / out-of-context methylated /
                                           // unmethylated; 1,3 = skipped / doubled as is; 5,7 = the same when lower-cased
   ThrParams thr;
@@ -120,12 +121,11 @@ template <int T, int NP, bool LEAN = false> struct Cx2Lds {
   uint32_t *wide, *cov;
 };
 
-// 16-entry byte LUT lookup of the four codes of a dword; pick0 = 0x03020100 or, for a lower-cased read, 0x07060504
-// (every byte takes the codes-8..15 half: c | 8, rcpp_cx_report.cpp:118,122)
-__device__ __forceinline__ uint32_t cx2_lut(uint32_t w, const ClassLut &F, uint32_t pick0) {
-  const uint32_t lo3 = w & 0x07070707u;
-  const uint32_t pick = ((w >> 1) & 0x04040404u) | pick0;
-  return __builtin_amdgcn_perm(__builtin_amdgcn_perm(F.hi1, F.hi0, lo3), __builtin_amdgcn_perm(F.lo1, F.lo0, lo3), pick);
+// 16-entry byte LUT lookup of the four codes of a dword in two v_perm_b32 (X: the table in lut16_xor_form, common.hpp);
+// low8 = 0 or, for a lower-cased read, 0x08080808 (every byte takes the codes-8..15 half: c | 8, rcpp_cx_report.cpp:118,122)
+__device__ __forceinline__ uint32_t cx2_lut(uint32_t w, const ClassLut &X, uint32_t low8) {
+  const uint32_t sel = (w & 0x0F0F0F0Fu) | low8;
+  return __builtin_amdgcn_perm(X.lo1, X.lo0, sel) ^ __builtin_amdgcn_perm(X.hi1, X.hi0, sel ^ 0x08080808u);
 }
 
 template <int G>
@@ -310,7 +310,7 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
 #pragma unroll
     for (int u = 0; u < NU; u++) {
 #pragma unroll
-      for (int d = 0; d < 4; d++) w[u][d] = (EPI_CX_ABLATE & 4) ? w[u][d] : cx2_lut(w[u][d], a.lut_s, 0x03020100u);
+      for (int d = 0; d < 4; d++) w[u][d] = (EPI_CX_ABLATE & 4) ? w[u][d] : cx2_lut(w[u][d], a.lut_sx, 0u);
       const uint32_t t = (w[u][0] & 0x55555555u) + (w[u][1] & 0x55555555u) + (w[u][2] & 0x55555555u);
       const uint32_t d3 = w[u][3] & 0x55555555u;
       E += (t & 0x33333333u) + (d3 & 0x33333333u);
@@ -356,14 +356,14 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
     }
   } else {
     // calls of the reported contexts: one ds_add_u64 per dword and plane, only from lanes that hold a call
-    const uint32_t pick0 = g.ps == 0 ? 0x07060504u : 0x03020100u;   // failed the threshold: lower-cased (:118)
+    const uint32_t pick0 = g.ps == 0 ? 0x08080808u : 0u;            // failed the threshold: lower-cased (:118)
     uint32_t fl = 0;
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;      // (always: the visit stays inside the tile)
 #pragma unroll
       for (int d = 0; d < 4; d++) {
-        const uint32_t f = cx2_lut(w[u][d], a.lut_r, pick0);
+        const uint32_t f = cx2_lut(w[u][d], a.lut_rx, pick0);
         w[u][d] = f;
         fl |= f;
 #pragma unroll
@@ -1268,6 +1268,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   Cx2Args a;
   memset(&a, 0, sizeof(a));
   const int np = make_report_lut(ctx_mask, &a.lut_r, &a.ctx_of_plane);
+  a.lut_rx = lut16_xor_form(a.lut_r);
   const int T = cx_tile_for(np);
   RowStats st;
   int32_t nt = 0;
@@ -1281,6 +1282,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     uint32_t fill4 = 0;
     if (nt > 0 && np > 0 && cx_fused_fits(st.max_len) && make_fused_lut(*thr, a.ctx_of_plane, np, &a.lut_s, &fill4)) {
       fused = true;
+      a.lut_sx = lut16_xor_form(a.lut_s);
       a.thr = thr->prm;
       a.fill4 = fill4;
       a.pass_out = d_pass_out;

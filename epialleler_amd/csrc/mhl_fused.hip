@@ -221,11 +221,7 @@ __device__ __forceinline__ void mhlf_planes(const uint32_t (&ww)[4 * C], uint32_
   if constexpr (sizeof(M) == 8) { U |= (M)uhi << 32; N |= (M)nhi << 32; }
 }
 
-// 16-entry byte LUT lookup of the four codes of a dword in two v_perm_b32.  A selector byte of 0 .. 7 picks a byte of the
-// two table words; 8 .. 11 give the sign of table byte 1 / 3 / 5 / 7 in all eight bits, 12 gives 0x00 and 13 .. 15 give
-// 0xFF.  So perm(low half, code) is right for codes 0 .. 7 and a constant per code for 8 .. 15, perm(high half, code ^ 8)
-// the other way round, and with the halves stored as make_mhlf_lut2 stores them (complemented where the other lookup
-// answers 0xFF) the XOR of the two is the entry.
+// 16-entry byte LUT lookup of the four codes of a dword in two v_perm_b32 (F: a table in lut16_xor_form, common.hpp)
 __device__ __forceinline__ uint32_t mhlf_lut4(uint32_t w, const MhlLut &F) {
   const uint32_t sel = w & 0x0F0F0F0Fu;
   return __builtin_amdgcn_perm(F.lo1, F.lo0, sel) ^ __builtin_amdgcn_perm(F.hi1, F.hi0, sel ^ 0x08080808u);
@@ -841,13 +837,13 @@ static MhlLut make_mhlf_lut2(uint32_t ctx_mask) {
     if (!in && ((0xE400u >> code) & 1u)) f |= 16u;           // codes 10, 13, 14, 15: unmethylated
     if (code == 11) f |= 4u;                                 // skipped (:187)
     if (code == 3 || code == 4 || code == 8 || code == 9) f |= 64u;   // their counters are sums / the coverage slot (:190-194)
-    // (entries are below 128.  Stored complemented, an entry's sign bit is set, which is what the other half's lookup
-    // returns -- as 0xFF -- for selectors 8 .. 11 and 13 .. 15; selector 12, i.e. codes 4 and 12, returns 0x00)
-    if ((code & 7u) != 4u) f ^= 0xFFu;
     w[code >> 2] |= f << (8 * (code & 3));
   }
+  ClassLut d;
+  d.lo0 = w[0]; d.lo1 = w[1]; d.hi0 = w[2]; d.hi1 = w[3];
+  const ClassLut x = lut16_xor_form(d);                      // (the form mhlf_lut4 looks up)
   MhlLut l;
-  l.lo0 = w[0]; l.lo1 = w[1]; l.hi0 = w[2]; l.hi1 = w[3];
+  l.lo0 = x.lo0; l.lo1 = x.lo1; l.hi0 = x.hi0; l.hi1 = x.hi1;
   return l;
 }
 
