@@ -306,24 +306,37 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
     // One LUT lookup per dword, kept in place of the bytes.  Class totals of the whole row: 2-bit fields, three dwords
     // add field-wise (<= 3), split into even / odd 4-bit fields (<= 12 over three chunks), summed by v_sad_u8, two
     // counts per word over the group.
-    uint32_t E = 0, O = 0, cls[4] = {0, 0, 0, 0}, fl = 0;
+    uint32_t cls[4] = {0, 0, 0, 0}, fl = 0;
 #pragma unroll
     for (int u = 0; u < NU; u++) {
 #pragma unroll
       for (int d = 0; d < 4; d++) w[u][d] = (EPI_CX_ABLATE & 4) ? w[u][d] : cx2_lut(w[u][d], a.lut_sx, 0u);
-      const uint32_t t = (w[u][0] & 0x55555555u) + (w[u][1] & 0x55555555u) + (w[u][2] & 0x55555555u);
-      const uint32_t d3 = w[u][3] & 0x55555555u;
-      E += (t & 0x33333333u) + (d3 & 0x33333333u);
-      O += ((t >> 2) & 0x33333333u) + ((d3 >> 2) & 0x33333333u);
       fl |= w[u][0] | w[u][1] | w[u][2] | w[u][3];
-      if (u % 3 == 2 || u == NU - 1) {
-        cls[0] = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, cls[0]);         // in context (either case)
-        cls[2] = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, cls[2]);  // out of context, methylated
-        cls[1] = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, cls[1]);         // in context, methylated
-        cls[3] = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, cls[3]);  // out of context, unmethylated
-        E = 0; O = 0;
-      }
     }
+    // The odd bits of a LUT byte are the flags of the skipped / doubled codes; they have to be masked off before three
+    // dwords are added field-wise -- unless no byte of the wavefront's rows carries one (the usual case: WGS reads whose
+    // mates meet), which the OR of the lookups tells.
+    auto count = [&](auto masked) {
+      constexpr bool MASKED = decltype(masked)::value;
+      constexpr uint32_t EV = MASKED ? 0x55555555u : 0xFFFFFFFFu;
+      uint32_t E = 0, O = 0;
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const uint32_t t = (w[u][0] & EV) + (w[u][1] & EV) + (w[u][2] & EV);
+        const uint32_t d3 = w[u][3] & EV;
+        E += (t & 0x33333333u) + (d3 & 0x33333333u);
+        O += ((t >> 2) & 0x33333333u) + ((d3 >> 2) & 0x33333333u);
+        if (u % 3 == 2 || u == NU - 1) {
+          cls[0] = __builtin_amdgcn_sad_u8(E & 0x0F0F0F0Fu, 0u, cls[0]);         // in context (either case)
+          cls[2] = __builtin_amdgcn_sad_u8((E >> 4) & 0x0F0F0F0Fu, 0u, cls[2]);  // out of context, methylated
+          cls[1] = __builtin_amdgcn_sad_u8(O & 0x0F0F0F0Fu, 0u, cls[1]);         // in context, methylated
+          cls[3] = __builtin_amdgcn_sad_u8((O >> 4) & 0x0F0F0F0Fu, 0u, cls[3]);  // out of context, unmethylated
+          E = 0; O = 0;
+        }
+      }
+    };
+    if (__builtin_expect(__ballot((fl & 0xAAAAAAAAu) != 0u) == 0ull, 1)) count(std::false_type{});
+    else count(std::true_type{});
     const uint32_t s01 = cx2_group_sum<G>(cls[0] | (cls[1] << 16)), s23 = cx2_group_sum<G>(cls[2] | (cls[3] << 16));
     const uint32_t n_all = s01 & 0xFFFFu, n_m = s01 >> 16;
     g.ps = a.thr_tab ? cx2_threshold_tab(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr, a.thr_tab)
