@@ -213,6 +213,8 @@ struct Options {
   int mhl_group_g = 0, mhl_group_c = 0;   // EPIHIP_MHL_GROUP="G,C"
   int mhl_sums = 0;          // EPIHIP_MHL_SUMS      32 / 64
   int mhlf_shape = 0;        // EPIHIP_MHLF_SHAPE="G,CA[,CB]"  lane shape of the one-pass lMHL kernel, as G * 100 + CA * 10 + CB
+  int mhlf_fold = -1;        // EPIHIP_MHLF_FOLD=0/1 one-pass lMHL kernel without / with the LDS array of folded call counters (-1: by the batch)
+  int mhlf_fold_slots = -1;  // EPIHIP_MHLF_FOLD_SLOTS  slab slots of the kernel without it (-1: default)
   int pr_group = 0;          // EPIHIP_GROUP         lanes per read of the general per-read kernel
   int pr_rpg = 0;            // EPIHIP_PR_RPG
   int pr_wide = 1;           // EPIHIP_PR_WIDE=0

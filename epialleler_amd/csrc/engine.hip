@@ -1,6 +1,7 @@
 // Engine plumbing: errors, device buffers, engine/batch lifetime, pinned
 // double-buffered upload, small synchronous read-backs, HIP-event profiling.
 #include "common.hpp"
+#include <sys/mman.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -270,6 +271,15 @@ static int ensure_staging(epi_engine *eng) {
   return EPI_OK;
 }
 
+// A large pageable destination that has not been touched yet (a column the caller has just allocated) is faulted in by the
+// copy below: with transparent huge pages in `madvise` mode the hint turns ~40 000 4 KiB faults of a 10 M-row table into ~80.
+static void advise_huge(void *p, size_t n) {
+  if (n < (4u << 20) || options().no_hugepage) return;
+  const uintptr_t two = (uintptr_t)2 << 20;
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + two - 1) & ~(two - 1), hi = (reinterpret_cast<uintptr_t>(p) + n) & ~(two - 1);
+  if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+}
+
 int copy_parts_to_host(epi_engine *eng, const CopyPart *parts, int nparts, hipStream_t s) {
   const size_t piece = 8u << 20;                           // (the staging buffers hold 64 MiB each; 8 MiB pieces keep the
                                                            // first copy-out early and the last one short)
@@ -289,6 +299,7 @@ int copy_parts_to_host(epi_engine *eng, const CopyPart *parts, int nparts, hipSt
     const CopyPart &p = parts[i];
     if (!p.bytes) continue;
     if (is_pinned_host(p.dst)) { EPI_HIP(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, s)); continue; }
+    advise_huge(p.dst, p.bytes);
     if (!staged) {
       EPI_TRY(ensure_staging(eng));
       for (int j = 0; j < 2; j++) EPI_HIP(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));

@@ -53,6 +53,8 @@ static void read_options() {
     if (nf >= 2 && (g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && ca >= 2 && ca <= 4 && (nf == 2 || cb == 0 || two))
       o.mhlf_shape = g * 100 + ca * 10 + (nf == 3 ? cb : 0);
   }
+  if (const char *e = getenv("EPIHIP_MHLF_FOLD")) o.mhlf_fold = atoi(e) != 0;
+  geti("EPIHIP_MHLF_FOLD_SLOTS", &o.mhlf_fold_slots);
   geti("EPIHIP_GROUP", &o.pr_group);
   geti("EPIHIP_PR_RPG", &o.pr_rpg);
   if (const char *e = getenv("EPIHIP_PR_WIDE")) o.pr_wide = atoi(e) != 0;

@@ -993,13 +993,15 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   // LDS (five per CU instead of four) and a tile of more than 255 rows folds its u8 counters into a slot of a slab in HBM
   // (MHLF_FOLD_SLOTS of them; a tile that finds none left goes to the WIDE variant with the other deep tiles).  Batches whose
   // tiles average well below 255 rows start there; one that runs out of slots switches the batch over.
-  const bool fold = b->mhlf_prefer_fold || (double)b->n > 150.0 * (double)nt;
+  const bool fold = options().mhlf_fold >= 0 ? options().mhlf_fold != 0 : (b->mhlf_prefer_fold || (double)b->n > 150.0 * (double)nt);
+  const uint32_t fold_slots = options().mhlf_fold_slots >= 0 && (uint32_t)options().mhlf_fold_slots < MHLF_FOLD_SLOTS
+                                  ? (uint32_t)options().mhlf_fold_slots : MHLF_FOLD_SLOTS;   // (test hook: fewer)
   a.max_rows = MHLF_FAST_ROWS;
   a.fold_slab = nullptr; a.fold_cursor = b->misc.as<uint32_t>() + 5; a.fold_slots = 0;
   if (!fold) {
     EPI_TRY(b->mhlf_fold_slab.ensure((size_t)MHLF_FOLD_SLOTS * 2 * T * 4));
     a.fold_slab = b->mhlf_fold_slab.as<uint32_t>();
-    a.fold_slots = MHLF_FOLD_SLOTS;
+    a.fold_slots = fold_slots;
   }
   if (options().heavy_rows > 0 && options().heavy_rows < a.max_rows) a.max_rows = options().heavy_rows;   // test hook (EPIHIP_HEAVY_ROWS)
   a.slot_rows = slot;
@@ -1051,7 +1053,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
       host4[1] = again[0]; host4[2] = again[1];
       b->mhlf_prefer_wide = host4[3] > (uint32_t)nt / 2;   // most tiles needed the wide sums: start there next time
     }
-    if (!fold && host4[5] > MHLF_FOLD_SLOTS / 2) b->mhlf_prefer_fold = true;   // many tiles over 255 rows: LDS fold array next time
+    if (!fold && host4[5] > fold_slots / 2) b->mhlf_prefer_fold = true;   // many tiles over 255 rows: LDS fold array next time
     host[0] = host4[1]; host[1] = host4[2]; host[2] = host4[3];
 #ifdef EPI_CHECK
     {

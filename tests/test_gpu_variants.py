@@ -27,6 +27,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},                # lMHL (fused kernel): nearly every tile outgrows its pool slot
     {"EPIHIP_MHL_SLOT": "0"},
     {"EPIHIP_HEAVY_ROWS": "40"},                                         # fused lMHL kernel gives up on tiles with > 40 rows: two-kernel path
+    {"EPIHIP_MHLF_FOLD": "0"},                                           # one-pass lMHL kernel without the LDS fold array: tiles over 255 rows
+                                                                         # fold their call counters into slab slots in HBM
+    {"EPIHIP_MHLF_FOLD": "0", "EPIHIP_MHLF_FOLD_SLOTS": "1"},            # ... and find no slot left: the WIDE variant takes them
+    {"EPIHIP_MHLF_FOLD": "1"},                                           # ... with it, whatever the batch looks like
     {"EPIHIP_MHL_FUSED": "0"},                                           # lMHL: the two-kernel path (records) for every batch
     {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_SLOT": "2", "EPIHIP_HEAVY_ROWS": "500"},
     {"EPIHIP_MHL_FUSED": "0", "EPIHIP_MHL_SLOT": "0"},
