@@ -24,7 +24,7 @@ for p in "$PASSES".split():
             k = r["Kernel_Name"][:48]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in sorted(acc.items()):
-            if "cx_" in k or "per_read" in k or "mhl" in k or "tile_pass" in k:
+            if "cx_" in k or "cxp" in k or "per_read" in k or "mhl" in k or "tile_pass" in k:
                 for c, v in sorted(d.items()):
                     print("%-50s %-24s %14.0f  (n=%d)" % (k, c, sum(v)/len(v), len(v)))
 PY
