@@ -346,6 +346,31 @@ def test_lmhl_sum_width_and_lowered_heavy_threshold(ea):
         bam.close()
 
 
+def test_two_kernel_lmhl_index_boundaries(ea, hook_env):
+    """The three index computations of the two-kernel lMHL path ("index bounds"): reads whose last
+    byte is the last position of a 512-position tile and the last byte of the batch, reads that end one position
+    before / behind that, a long read (per-block records) that fills its last 2 KiB record block to the final byte,
+    and stretches that run up to the last byte -- with the one-pass kernel switched off, plain and wavefront-per-read."""
+    def reads(lens, ends):
+        xms = ["".join("Zz"[(i * 7 + k) % 5 == 0] if (i + k) % 3 else "." for i in range(n)) for k, n in enumerate(lens)]
+        xms = [x[:-3] + "ZZZ" for x in xms]                              # a stretch up to the last byte
+        return H.templates_from_xm(xms, [e - n + 1 for n, e in zip(lens, ends)], [1 + (k & 1) for k in range(len(lens))])
+    for multi in ("", "1"):
+        hook_env("EPIHIP_MHL_FUSED", "0")
+        if multi:
+            hook_env("EPIHIP_MHL_MULTI", "1")
+        for lens, ends in (([100, 300, 511, 512, 513, 700], [1023, 1024, 1535, 2047, 2048, 2559]),   # ends on / around tile ends
+                           ([2048, 4096, 6144, 2047, 2049], [4095, 8191, 12287, 12288, 16383]),         # whole record blocks
+                           ([5000] * 4, [8191, 8192, 8193, 10239])):
+            t = reads(lens, ends)
+            bam = pb(ea, t)
+            for hmax, hmin in ((0, 0), (3, 2)):
+                got = ea.rcpp_mhl_report(bam, "Zz", hmax, hmin, 1.0)
+                want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, hmin, 1.0)
+                H.assert_reports_equal(dict(got), want, float_cols=("length", "lmhl"))
+            bam.close()
+
+
 def test_long_reads(ea):
     rng = np.random.default_rng(29)
     t = synth_np.random_templates(rng, 40, 5000, 12000, 2, 30000, alphabet="......hhxzzZZZHXuU-")
