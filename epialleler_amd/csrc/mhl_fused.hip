@@ -413,22 +413,23 @@ __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool fold
   __syncthreads();
   // PPT consecutive positions per thread, both strands; key order: position, then '+' before '-'
   const int p0 = PPT * (int)threadIdx.x;
+  auto calls = [&](int p, int sd) -> uint32_t {
+    if (!folded) return (s_n8[sd * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
+    if constexpr (NW32) return s_nw[sd * T + p];
+    else return (s_nw[sd * (T / 2) + (p >> 1)] >> (16 * (p & 1))) & 0xFFFFu;
+  };
   uint32_t okm = 0, nr = 0;                                // bit 2 j + s: cell (p0 + j, strand s) is a row of the table
-  uint32_t nn[2 * PPT];
 #pragma unroll
   for (int j = 0; j < PPT; j++) {
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int sd = 0; sd < 2; sd++) {
       const int p = p0 + j;
-      uint32_t n, c;
-      if (!folded) n = (s_n8[s * Q + (p >> 2)] >> (8 * (p & 3))) & 255u;
-      else if constexpr (NW32) n = s_nw[s * T + p];
-      else n = (s_nw[s * (T / 2) + (p >> 1)] >> (16 * (p & 1))) & 0xFFFFu;
-      if constexpr (WIDE) c = s_cov[s * T + p];
-      else { const uint32_t v = s_cov[p]; c = s ? v >> 16 : v & 0xFFFFu; }
-      nn[2 * j + s] = n;
+      const uint32_t n = calls(p, sd);
+      uint32_t c;
+      if constexpr (WIDE) c = s_cov[sd * T + p];
+      else { const uint32_t v = s_cov[p]; c = sd ? v >> 16 : v & 0xFFFFu; }
       const bool ok = n > (c >> 1);                                              // :76-86
-      okm |= ok ? 1u << (2 * j + s) : 0u;
+      okm |= ok ? 1u << (2 * j + sd) : 0u;
       nr += ok;
     }
   }
@@ -455,20 +456,30 @@ __device__ __forceinline__ void mhlf_emit(const MhlFArgs &a, int tile, bool fold
   }
   __syncthreads();
   const uint32_t total = s_scan[NW], base = s_scan[NW + 1];
-  if (total == 0xFFFFFFFFu || nr == 0u) return;
-  uint32_t w = base + s_scan[wave] + inc - nr;
+  if (total == 0xFFFFFFFFu || total == 0u) return;
+  // The rows of a tile are few (a few per cent of its cells): the cells are listed in key order -- in the coverage array,
+  // which nobody reads any more -- and written densely, one row per lane with consecutive addresses, instead of every
+  // thread walking its own eight cells.
+  uint16_t *list = reinterpret_cast<uint16_t *>(s_cov);
+  {
+    uint32_t k = s_scan[wave] + inc - nr;
 #pragma unroll
-  for (int i = 0; i < 2 * PPT; i++) {
-    if (!((okm >> i) & 1u)) continue;
-    const int p = p0 + (i >> 1), s = i & 1;
-    if (EPI_DEV_CHECK(a.dbg, w < a.pool_cap, 33, w, a.pool_cap)) {
-      a.pool_key[w] = ((uint32_t)p << 4) | ((uint32_t)s << 3) | a.ctx;
-      a.pool_cov[w] = nn[i];                                                     // coverage column, :90
-      a.pool_nu[w] = (unsigned long long)s_sum[(0 + s) * T + p];                 // :93 numerator
-      a.pool_hs[w] = (unsigned long long)s_sum[(2 + s) * T + p];                 // :92 numerator
-      a.pool_de[w] = (unsigned long long)s_sum[(4 + s) * T + p];                 // :93 denominator
+    for (int i = 0; i < 2 * PPT; i++) {
+      if ((okm >> i) & 1u) { list[k] = (uint16_t)(2 * (p0 + (i >> 1)) + (i & 1)); k++; }
     }
-    w++;
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < total; j += WG) {
+    const uint32_t id = list[j];
+    const int p = (int)(id >> 1), sd = (int)(id & 1u);
+    const uint32_t w = base + j;
+    if (EPI_DEV_CHECK(a.dbg, w < a.pool_cap, 33, w, a.pool_cap)) {
+      a.pool_key[w] = ((uint32_t)p << 4) | ((uint32_t)sd << 3) | a.ctx;
+      a.pool_cov[w] = calls(p, sd);                                              // coverage column, :90
+      a.pool_nu[w] = (unsigned long long)s_sum[(0 + sd) * T + p];                // :93 numerator
+      a.pool_hs[w] = (unsigned long long)s_sum[(2 + sd) * T + p];                // :92 numerator
+      a.pool_de[w] = (unsigned long long)s_sum[(4 + sd) * T + p];                // :93 denominator
+    }
   }
 }
 
