@@ -49,7 +49,10 @@ namespace epi {
 #define EPI_MHLF_ABLATE 0                         // 1: no emit, 2: no row analysis (loads only), 4: no stretch runs, 8: no call counters
 #endif
 constexpr int MHLF_WG = EPI_MHLF_WG, MHLF_NW = MHLF_WG / 64, MHLF_Q = MHLF_T / 4;
-constexpr int MHLF_WG2 = 256;                     // workgroup of the two-block lane shapes
+#ifndef EPI_MHLF_WG2
+#define EPI_MHLF_WG2 256
+#endif
+constexpr int MHLF_WG2 = EPI_MHLF_WG2;                     // workgroup of the two-block lane shapes
 constexpr int MHLF_FOLD = 255;                    // u8 call counters: a row adds at most 1 per position
 constexpr int MHLF_STAB = 256;                    // S(k) table entries in LDS
 constexpr uint32_t MHLF_FOLD_SLOTS = 2048;        // slab slots (8 KB each) of the kernels built without the LDS fold array
