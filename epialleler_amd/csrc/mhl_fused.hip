@@ -42,9 +42,6 @@ namespace epi {
 #ifndef EPI_MHLF_WPS
 #define EPI_MHLF_WPS 8
 #endif
-#ifndef EPI_MHLF_PIPE
-#define EPI_MHLF_PIPE 0                           // two-block shapes: byte loads one step ahead
-#endif
 #ifndef EPI_MHLF_ABLATE
 #define EPI_MHLF_ABLATE 0                         // 1: no emit, 2: no row analysis (loads only), 4: no stretch runs, 8: no call counters
 #endif
@@ -649,10 +646,8 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
   // ---- accumulate: the next step's row columns are fetched early; the u8 call counters are folded every MHLF_FOLD rows ----
   for (int blo = td.row_lo; blo < td.row_hi; blo += MHLF_FOLD) {
     const int bhi = td.row_hi - blo > MHLF_FOLD ? blo + MHLF_FOLD : td.row_hi;
-    // Row columns are fetched one step ahead.  PIPE (the two-block shapes: four waves per SIMD, registers to spare): the
-    // row's BYTES are fetched a step ahead too -- the loads of step i + 1 are issued before step i is analysed, so a
-    // wavefront hides its own memory latency instead of relying on the other waves of the SIMD.
-    constexpr bool PIPE = CB > 0 && EPI_MHLF_PIPE;
+    // Row columns are fetched one step ahead.  (The row's bytes a step ahead as well -- 106 VGPRs -- changed nothing: the
+    // kernel does not wait for memory, profiles/r03_mhl_ablation.txt.)
     int64_t n_rs = 0, n_re = 0;                             // columns of the next row this lane loads bytes for
     int32_t n_st = 0, n_sd = 1;
     auto load_cols = [&](int rr) {
@@ -669,28 +664,13 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
       if (__builtin_expect(use_buf && __ballot(out) == 0ull, 1)) return mhlf_load_buf<C>(buf, g32, lo0, lo0 + g.len, g.valid);
       return g.valid ? mhlf_load<C>(a.xm, a.xm_cap, n_rs - lo0, lo0, lo0 + g.len) : ChunkRaw<C>{{0}, 0, 0};
     };
-    Geo gq = {0, 0, 1, false};                              // PIPE: geometry of the row whose bytes are in `rawq`
-    ChunkRaw<C> rawq = {{0}, 0, 0};
-    {
-      const int r0 = blo + wave * R + grp;
-      load_cols(r0);
-      if constexpr (PIPE) { gq = geo_of(r0); rawq = load_bytes(gq); load_cols(r0 + NW * R); }
-    }
+    load_cols(blo + wave * R + grp);
     for (int rbase = blo + wave * R; rbase < bhi; rbase += NW * R) {
       const int r = rbase + grp;
       if (!EPI_DEV_CHECK(a.dbg, r >= bhi || (r >= 0 && r < a.nrows), 31, r, 0)) return;
-      Geo g;
-      ChunkRaw<C> raw;
-      if constexpr (PIPE) {
-        g = gq; raw = rawq;
-        gq = geo_of(r + NW * R);                                              // the next row: its bytes go out now,
-        rawq = load_bytes(gq);
-        load_cols(r + 2 * NW * R);                                            // and the columns of the one after
-      } else {
-        g = geo_of(r);
-        raw = load_bytes(g);
-        load_cols(r + NW * R);                                                // (in flight with the bytes)
-      }
+      const Geo g = geo_of(r);
+      ChunkRaw<C> raw = load_bytes(g);
+      load_cols(r + NW * R);                                                  // (in flight with the bytes)
       const bool valid = g.valid;
       const int32_t rel = g.rel, len = g.len, sd = g.sd;                      // tile position of the row's byte 0, its bytes, strand
       if (!EPI_DEV_CHECK(a.dbg, !valid || (len >= 0 && len <= G * W), 32, r, len)) return;
