@@ -1027,6 +1027,7 @@ __global__ __launch_bounds__(CX_WG, 8) void k_cxp_tiles(Cx2Args a, int ntiles, i
     if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
     return;
   }
+  if (EPI_CX_ABLATE & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }   // timing builds: no emit
   cx2_emit<CXP_T, 3>(a, tile, cxp_source(a, cnt), s_scan, s_list);
 }
 
@@ -1055,6 +1056,8 @@ __global__ __launch_bounds__(CX_WG, 8) void k_cxp_heavy(Cx2Args a, int np) {
   }
 }
 
+struct __attribute__((packed, aligned(4))) CxU4u { uint32_t x, y, z, w; };   // 16 bytes at any dword address
+
 // One wavefront per tile copies the tile's rows from the pool to their place in the final table
 // (offset = exclusive scan of the tile row counts) and decodes them: contiguous reads, contiguous writes.
 __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tiles, const uint32_t *__restrict__ tile_out,
@@ -1071,7 +1074,24 @@ __global__ __launch_bounds__(256) void k_cx_gather(const Tile *__restrict__ tile
   const int lane = threadIdx.x & 63;
   const Tile td = tiles[tile];
   const uint32_t src0 = tile_base[tile], dst0 = tile_out[tile];
-  for (uint32_t i = lane; i < n; i += 64) {
+  // four consecutive rows per lane and instruction (16-byte loads and stores, any alignment: 1 KiB per wavefront
+  // instruction instead of 256 bytes), the last few rows of the tile one by one
+  const uint32_t n4 = n & ~3u;
+  for (uint32_t i = 4u * lane; i < n4; i += 256) {
+    const CxU4u key = *reinterpret_cast<const CxU4u *>(pool_key + src0 + i);
+    const CxU4u me = *reinterpret_cast<const CxU4u *>(pool_meth + src0 + i);
+    const CxU4u un = *reinterpret_cast<const CxU4u *>(pool_unmeth + src0 + i);
+    const uint32_t o = dst0 + i;
+    const uint32_t rn = (uint32_t)td.rname;
+    const uint32_t p0 = (uint32_t)td.pos0;
+    *reinterpret_cast<CxU4u *>(o_rname + o) = CxU4u{rn, rn, rn, rn};
+    *reinterpret_cast<CxU4u *>(o_strand + o) = CxU4u{1u + ((key.x >> 3) & 1u), 1u + ((key.y >> 3) & 1u), 1u + ((key.z >> 3) & 1u), 1u + ((key.w >> 3) & 1u)};
+    *reinterpret_cast<CxU4u *>(o_pos + o) = CxU4u{p0 + (key.x >> 4), p0 + (key.y >> 4), p0 + (key.z >> 4), p0 + (key.w >> 4)};
+    *reinterpret_cast<CxU4u *>(o_ctx + o) = CxU4u{key.x & 7u, key.y & 7u, key.z & 7u, key.w & 7u};
+    *reinterpret_cast<CxU4u *>(o_meth + o) = me;
+    *reinterpret_cast<CxU4u *>(o_unmeth + o) = un;
+  }
+  for (uint32_t i = n4 + lane; i < n; i += 64) {
     const uint32_t key = pool_key[src0 + i];
     const uint32_t o = dst0 + i;
     o_rname[o] = td.rname;
