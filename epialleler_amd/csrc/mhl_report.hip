@@ -840,7 +840,30 @@ __global__ __launch_bounds__(256) void k_mhl_gather(const Tile *__restrict__ til
   const int lane = threadIdx.x & 63;
   const Tile td = tiles[tile];
   const uint32_t src0 = tile_base[tile], dst0 = tile_out[tile];
-  for (uint32_t i = lane; i < n; i += 64) {
+  // two consecutive rows per lane and instruction (8- / 16-byte loads and stores at any dword / qword address), an odd
+  // last row on its own
+  struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
+  struct __attribute__((packed, aligned(8))) Q2 { unsigned long long x, y; };
+  struct __attribute__((packed, aligned(8))) D2 { double x, y; };
+  const uint32_t n2 = n & ~1u;
+  const uint32_t rn = (uint32_t)td.rname, p0 = (uint32_t)td.pos0;
+  for (uint32_t i = 2u * lane; i < n2; i += 128) {
+    const U2 key = *reinterpret_cast<const U2 *>(pool_key + src0 + i);
+    const U2 cov = *reinterpret_cast<const U2 *>(pool_cov + src0 + i);
+    const Q2 hs = *reinterpret_cast<const Q2 *>(pool_hs + src0 + i);
+    const Q2 nu = *reinterpret_cast<const Q2 *>(pool_nu + src0 + i);
+    const Q2 de = *reinterpret_cast<const Q2 *>(pool_de + src0 + i);
+    const uint32_t o = dst0 + i;
+    *reinterpret_cast<U2 *>(o_rname + o) = U2{rn, rn};
+    *reinterpret_cast<U2 *>(o_strand + o) = U2{1u + ((key.x >> 3) & 1u), 1u + ((key.y >> 3) & 1u)};
+    *reinterpret_cast<U2 *>(o_pos + o) = U2{p0 + (key.x >> 4), p0 + (key.y >> 4)};
+    *reinterpret_cast<U2 *>(o_ctx + o) = U2{key.x & 7u, key.y & 7u};
+    *reinterpret_cast<U2 *>(o_cov + o) = cov;                                          // :90
+    *reinterpret_cast<D2 *>(o_len + o) = D2{(double)hs.x / (double)(int)cov.x, (double)hs.y / (double)(int)cov.y};   // :92
+    *reinterpret_cast<D2 *>(o_lmhl + o) = D2{(double)nu.x / (double)de.x, (double)nu.y / (double)de.y};             // :93
+  }
+  if (n2 < n && lane == 0) {
+    const uint32_t i = n2;
     const uint32_t key = pool_key[src0 + i];
     const uint32_t o = dst0 + i;
     o_rname[o] = td.rname;
