@@ -899,7 +899,10 @@ __global__ __launch_bounds__(CX_WG) void k_cx_emit_slab(Cx2Args a, const int32_t
 // (Z,z)][T] with the byte order rotated per lane so that the 32 lanes of a half-wave hit 32 different banks
 // (tile_common.hpp: cx_add_dword).  After the rows the counters are rewritten in place into what the common emit
 // reads: plane 0 = coverage, context planes = n | M << 16.
-constexpr int CXP_T = 1024;
+#ifndef EPI_CXP_T
+#define EPI_CXP_T 1024                        // (timing builds vary it)
+#endif
+constexpr int CXP_T = EPI_CXP_T;
 
 template <int G, int U0, int U1>
 __device__ __forceinline__ void cxp_add_range(const uint32_t (&w)[CX_NU], const RowSlice &cur) {
