@@ -59,6 +59,51 @@ __global__ __launch_bounds__(256) void k_rows_small(const uint8_t *__restrict__ 
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the one-pass lMHL kernel's shape: G lanes per row, each lane NU CONTIGUOUS 16-byte chunks (unaligned: the row's own
+// byte offset), so one instruction reads G pieces of 16 bytes that lie 16 * NU bytes apart
+template <int G, int NU, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_rows_lane(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & (G - 1));
+  const int64_t row = gid / G;
+  const int64_t rs = ALIGNED ? (row * L) & ~(int64_t)15 : row * L;
+  uint32_t acc = 0;
+  U4u w[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int64_t b = rs + 16 * (sub * NU + u);
+    U4u z = {0, 0, 0, 0};
+    w[u] = (row < n && b < rs + L + 15) ? *reinterpret_cast<const U4u *>(xm + b) : z;
+  }
+#pragma unroll
+  for (int u = 0; u < NU; u++) acc ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+// candidate lMHL shape: 4 lanes per row, a lane holds bytes [32 s, +32), [128 + 32 s, +32), [256 + 16 s, +16) of the row's
+// 320-byte window: two instructions read 16-byte pieces 32 bytes apart (the pair covers 128 contiguous bytes of the row),
+// the fifth reads 64 contiguous bytes
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_rows_32(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & 3);
+  const int64_t row = gid >> 2;
+  const int64_t rs = ALIGNED ? (row * L) & ~(int64_t)15 : row * L;
+  const int off[5] = {32 * sub, 32 * sub + 16, 128 + 32 * sub, 128 + 32 * sub + 16, 256 + 16 * sub};
+  U4u w[5];
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    U4u z = {0, 0, 0, 0};
+    w[u] = (row < n && off[u] < L + 15) ? *reinterpret_cast<const U4u *>(xm + rs + off[u]) : z;
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 5; u++) acc ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <int NU>
 __global__ __launch_bounds__(256) void k_stream(const uint8_t *__restrict__ xm, int64_t nchunks, uint32_t *out) {
   const int64_t base = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) * NU + (threadIdx.x & 63);
@@ -98,6 +143,11 @@ int main() {
   timeit("H  8 lanes x 5 8-byte loads  (8 rows/instr, 64 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows_small<8, 5, uint2>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
   timeit("I  4 lanes x 10 8-byte loads (16 rows/instr, 32 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows_small<4, 10, uint2>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
   timeit("J  8 lanes x 3 16-byte loads, 1 row (8 rows/instr, 128 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<8, 3, 1>), dim3(grid(8, 1)), dim3(256), 0, 0, xm, n, out); });
+  timeit("K  4 lanes x 5 contiguous 16-byte loads per lane, unaligned (lMHL kernel)", bytes, [&] { hipLaunchKernelGGL((k_rows_lane<4, 5, false>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("K2 the same, 16-byte aligned", bytes, [&] { hipLaunchKernelGGL((k_rows_lane<4, 5, true>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("K3 8 lanes x 3 contiguous 16-byte loads per lane, unaligned", bytes, [&] { hipLaunchKernelGGL((k_rows_lane<8, 3, false>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("M  4 lanes: 32 + 32 + 16 bytes per lane, 32-byte interleave, unaligned", bytes, [&] { hipLaunchKernelGGL((k_rows_32<false>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  timeit("M2 the same, 16-byte aligned", bytes, [&] { hipLaunchKernelGGL((k_rows_32<true>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
   const int64_t nch = bytes / 16;
   timeit("D  plain stream, 10 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<10>), dim3((unsigned)((nch / 10 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
   timeit("D4 plain stream, 4 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<4>), dim3((unsigned)((nch / 4 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
