@@ -628,7 +628,10 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
     z = reinterpret_cast<uint4 *>(s_sum);
     for (int i = threadIdx.x; i < (int)(6 * T * sizeof(ST) / 16); i += WG) z[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x == 0) s_hmax = 0u;
-    if (threadIdx.x < MHLF_STAB) s_tab[threadIdx.x] = (uint32_t)nrS(threadIdx.x);
+    if (threadIdx.x < MHLF_STAB) {                         // S(k) = k (k + 1) (k + 2) / 6 (= k below 2): 32 bits hold it for k < 256
+      const uint32_t k = threadIdx.x;
+      s_tab[k] = (k * (k + 1u) * (k + 2u)) / 6u;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -772,10 +775,16 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
     }
     if constexpr (!WIDE) {                                 // (one LDS atomic per wavefront and block of rows)
       if (__ballot(hmax != 0u) != 0ull) {
+        // maximum over the wavefront: four DPP steps inside a row of 16 lanes, then the four rows through SGPRs
         uint32_t m = hmax;
+        { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true); m = o > m ? o : m; }    // quad_perm [1,0,3,2]
+        { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true); m = o > m ? o : m; }    // quad_perm [2,3,0,1]
+        { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, true); m = o > m ? o : m; }   // row_half_mirror
+        { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, true); m = o > m ? o : m; }   // row_mirror
+        uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)m, 0);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
-        if (lane == 0) atomicMax(&s_hmax, m);
+        for (int rr = 1; rr < 4; rr++) { const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * rr); mw = o > mw ? o : mw; }
+        if (lane == 0) atomicMax(&s_hmax, mw);
       }
     }
     if (bhi < td.row_hi || nrows > MHLF_FOLD) { __syncthreads(); mhlf_fold<WIDE || !FOLD, WG>(s_n8, nw); }   // (deep tiles only)
