@@ -154,8 +154,10 @@ __device__ __forceinline__ ChunkRaw<C> mhlf_load_buf(__amdgpu_buffer_rsrc_t rs, 
   const int32_t hiv = any ? hi0 : 0;
 #pragma unroll
   for (int j = 0; j < C; j++) {
+    // (16 j travels as the scalar offset, which the range check leaves out: an out-of-range lane stays out of range, and
+    //  the caller has made sure an in-range lane's W bytes all lie inside the descriptor -- two VALU per chunk)
     const int32_t vo = 16 * j < hiv ? g32 : (int32_t)0x80000000u;
-    const MhlfU4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * j, 0, 0);   // (16 j: the instruction's offset field)
+    const MhlfU4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 16 * j, 0);
     r.ww[4 * j] = w.x; r.ww[4 * j + 1] = w.y; r.ww[4 * j + 2] = w.z; r.ww[4 * j + 3] = w.w;
   }
   return r;
@@ -537,8 +539,8 @@ __device__ __forceinline__ void mhlf_block(const MhlfRow<ST> &c, M U, M L, M K, 
   // calls of the context: u8 counters, one LDS atomic per two dwords of xm that hold any
   unsigned long long *n8 = reinterpret_cast<unsigned long long *>(c.n8 + (P0 >> 2));
 #pragma unroll
-  for (int e = 0; e < NPAIR; e++) {                        // (P0 is a multiple of 16: a pair is in or out of the tile together)
-    if (np[e] != 0u && (uint32_t)((P0 >> 2) + 2 * e) < (uint32_t)MHLF_Q && !(EPI_MHLF_ABLATE & 8))
+  for (int e = 0; e < NPAIR; e++) {                        // (P0 is a multiple of 16: the two pairs of a chunk are in or out of the tile together)
+    if (np[e] != 0u && (uint32_t)((P0 >> 2) + 4 * (e >> 1)) < (uint32_t)MHLF_Q && !(EPI_MHLF_ABLATE & 8))
       atomicAdd(n8 + e, (unsigned long long)((np[e] >> 3) & 0x01010101u) | ((unsigned long long)((np[e] >> 7) & 0x01010101u) << 32));
   }
   if (__builtin_expect(c.anyk, 0)) {
