@@ -1119,7 +1119,8 @@ static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : CXP_T; }
 // lane need ~80 VGPRs, which only the lean kernel's 256-thread workgroups have.  Returned as G * 8 + NU.
 static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
   const int64_t span = (fused ? (int64_t)max_len : (max_len < T ? max_len : T)) + (CX_CH - 1);
-  const int chunks = (int)((span + CX_CH - 1) / CX_CH);
+  int chunks = (int)((span + CX_CH - 1) / CX_CH);
+  if (!fused && chunks > T / CX_CH) chunks = T / CX_CH;    // (a slice is clipped to the tile's position-aligned chunks: never more than T / 16)
 #ifdef EPI_CX_FORCE_SHAPE                                  // timing builds only: (G, NU) = (EPI_CX_FORCE_SHAPE / 8, % 8)
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
