@@ -82,7 +82,8 @@ def _parse():
     ap.add_argument("--gather", action="store_true", help="N>1: also send every rank's rows to rank 0 inside the timed step")
     ap.add_argument("--check", action="store_true", help="N>1: rank 0 checks the FULL-size gathered table against a single-GPU "
                                                          "run of the whole stream (a reduced-size check always runs)")
-    ap.add_argument("--no-selfcheck", action="store_true", help="N>1: skip the reduced-size sharded == single-GPU check")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the self-check (N=1: the timed report against the oracle on "
+                                                                "row windows; N>1: reduced-size sharded == single-GPU tables)")
     ap.add_argument("--selfcheck-rows", type=int, default=600_000, help="N>1: total rows of the reduced-size check")
     ap.add_argument("--no-extras", action="store_true", help="only the contract fields (no streamed / d2h / cfg2u / strong_cfg3)")
     ap.add_argument("--strong-steps", type=int, default=3)
@@ -166,8 +167,8 @@ def n_chr_for(world):
     return 4 if world == 1 else 3
 
 
-def make_batch(cx, wl, rows, L, n_total, seed=42):
-    kw = dict(n_total=n_total, n_chr=n_chr_for(cx.world), seed=seed, row_first=cx.rank * rows, n=rows, device=cx.local)
+def make_batch(cx, wl, rows, L, n_total, seed=42, n_chr=None):
+    kw = dict(n_total=n_total, n_chr=n_chr or n_chr_for(cx.world), seed=seed, row_first=cx.rank * rows, n=rows, device=cx.local)
     stream = wl.get("stream", "uniform")
     if stream == "grid":
         return cx.synth.generate_device(read_len=L, **kw)
@@ -191,12 +192,12 @@ def make_step(cx, wl, bam, eng, gather):
                                              gather=gather, levels=bam.levels)
 
 
-def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False):
+def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=None):
     """W untimed + exactly K timed steps of `wl` on `rows` rows per rank, barrier + synchronize on both sides,
     max over ranks.  Returns a dict (and the batch / last report when keep=True)."""
     import ctypes as C
     n_total = rows * cx.world
-    bam = make_batch(cx, wl, rows, L, n_total)
+    bam = make_batch(cx, wl, rows, L, n_total, n_chr=n_chr)
     cx.torch.cuda.synchronize()
     eng = cx.D.HipShardEngine(bam) if cx.world > 1 else None
     step = make_step(cx, wl, bam, eng, gather)
@@ -273,6 +274,53 @@ def selfcheck(cx, n_total):
     return {"rows_total": n_total, "cx_rows": nrow, "ok": True, "all_reduce_bytes": {"cx": int(xb_cx), "mhl": int(xb_mhl)},
             "what": "sharded CX (thresholded) and lMHL tables, gathered on rank 0 over %s, bit-equal to the single-GPU tables of "
                     "the same stream; %d cuts inside chromosomes, shared tiles all-reduced" % (cx.args.backend, cx.world - 1)}
+
+
+def n1_selfcheck(cx, wl, res, L):
+    """N=1: the LAST TIMED report of the timed batch against the CPU oracle (the checker, never the thing measured) on
+    three row windows -- first, middle and last rows of the batch -- cut where no read outside the window can reach
+    (oracle/windows.py; rule: src/rcpp_cx_report.cpp:108-131, src/rcpp_mhl_report.cpp:138-198), plus strict
+    (rname, pos, strand) order of the whole table.  Integer columns bit-exact, float64 columns bitwise.  Untimed; raises
+    SystemExit on a mismatch."""
+    from oracle import windows as W
+    rows = res["rows"]
+    wrows = 20000 if L <= 1000 else max(300, 20000 * 300 // L)
+    letters = {"CG": "Z", "CHG": "X", "CHH": "H", "CxG": "ZX", "CX": "ZXH"}[wl.get("report_context", "CG")]
+    fn = W.oracle_for(wl["kind"], wl.get("threshold", False), letters)
+    t0 = time.perf_counter()
+    try:
+        r = W.check_windows(res["rep"], res["bam"].dev, rows, fn, float_cols=("length", "lmhl") if wl["kind"] == "mhl" else (),
+                            L=L, wrows=wrows, starts=(0, rows // 2, rows - wrows))
+    except AssertionError as e:
+        raise SystemExit("selfcheck FAILED: the timed report differs from the oracle: %s" % e)
+    r["seconds"] = round(time.perf_counter() - t0, 2)
+    r["what"] = ("the last timed report of the timed batch == the CPU oracle (oracle/epi_oracle.c) on %d-row windows at the "
+                 "first, middle and last rows (one read length trimmed at cut ends), all columns bit-exact; whole table in "
+                 "strict (rname, pos, strand) order" % wrows)
+    return r
+
+
+def tile_hint_off(cx, wl, res, steps):
+    """N=1 extra: the same step with EPIHIP_TILE_HINT=0 -- the tile index counted, scanned and asked for by every call
+    instead of rebuilt from the block offsets remembered from the first call on the batch."""
+    bam = res["bam"]
+    os.environ["EPIHIP_TILE_HINT"] = "0"
+    cx.lib.epi_options_reload()
+    try:
+        step = make_step(cx, wl, bam, None, False)
+        for _ in range(2):
+            step()
+        cx.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        cx.torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        del os.environ["EPIHIP_TILE_HINT"]
+        cx.lib.epi_options_reload()
+    return {"ms_per_step": round(ms, 4), "vs_hinted": round(ms / res["ms_per_step"], 3),
+            "what": "EPIHIP_TILE_HINT=0: count pass + scan + host round trip for the tile count in every step"}
 
 
 def streamed_and_d2h(cx, wl, res):
@@ -523,6 +571,9 @@ def main():
     bam, rep = res["bam"], res["rep"]
     n_total = res["n_total"]
 
+    if world == 1 and not args.no_selfcheck:
+        check = n1_selfcheck(cx, wl, res, L)
+
     if args.check and world > 1 and rank == 0 and wl["kind"] == "cx":
         # the whole stream on rank 0 alone, same generator arguments (n_chr_for(world): the genome of the sharded run)
         whole = make_batch(type("Whole", (), dict(world=world, rank=0, local=cx.local, synth=cx.synth))(), wl, n_total, L, n_total)
@@ -586,6 +637,8 @@ def main():
             "all_reduce_bytes_per_step": int(res["exchange_bytes"]), "selfcheck": check,
         }
     extras = not args.no_extras and not args.rows and not args.read_len
+    if world == 1 and extras and out is not None:
+        out["tile_hint_off"] = tile_hint_off(cx, wl, res, max(3, args.steps // 2))
     if world == 1 and extras and wl["kind"] == "cx" and L <= 1000 and out is not None:
         out["streamed"], out["d2h"] = streamed_and_d2h(cx, wl, res)
         out["host_out"] = host_out(cx, wl, res)
@@ -610,6 +663,14 @@ def main():
                     out[name] = {"value": round(u["n_total"] * k2 / u["dt"] / 1e6, 3), "unit": "Mreads/s",
                                  "ms_per_step": round(u["ms_per_step"], 4), "vs_cfg2": round(u["ms_per_step"] / res["ms_per_step"], 3),
                                  "kernel_ms_all": u["kernels"], "what": WORKLOADS[name]["desc"]}
+            # the comparator for N > 1 runs: N = 1 on THEIR stream (3 chromosomes, n_chr_for), so that a 1 -> N ratio
+            # divides numbers from the same genome layout
+            u = timed_run(cx, wl, rows, L, k2, 1, n_chr=n_chr_for(2))
+            if out is not None:
+                out["n1_same_stream"] = {"value": round(u["n_total"] * k2 / u["dt"] / 1e6, 3), "unit": "Mreads/s", "n_chr": n_chr_for(2),
+                                         "ms_per_step": round(u["ms_per_step"], 4), "kernel_ms_all": u["kernels"],
+                                         "what": "this workload at N = 1 on the stream the N > 1 runs use (3 chromosomes: every "
+                                                 "cut of equal row ranges lies inside a chromosome); the base for a 1 -> N ratio"}
         w3 = WORKLOADS["cfg3"]
         r3 = (w3["rows"] + world - 1) // world
         s3 = timed_run(cx, w3, r3, w3["read_len"], args.strong_steps, 1)

@@ -538,10 +538,37 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
     size_t total = 0;
     for (const Block &b : blocks) total += b.ulen;
     if (total >= ((size_t)8 << 20)) {
-      pin.cap = (total / 2 + ((size_t)1 << 20) + 15) / 16 * 16;
-      pin.th = std::thread([&pin]() {
+      // template bytes per inflated byte, sampled from the file's first records (sum of l_seq over sum of record sizes: a
+      // PE150 Bismark / DRAGEN file gives ~0.35, where the worst-case bound is 0.4): the buffer pinned ahead is sized by it
+      // plus 15 %; 0.5 when the sample cannot be read
+      double ratio = 0.5;
+      {
+        std::vector<Block> head;
+        size_t up = 0;
+        for (size_t i = 0; i < blocks.size() && head.size() < 4; i++) { Block b = blocks[i]; b.upos = up; up += b.ulen; head.push_back(b); }
+        std::vector<uint8_t> buf(up + 8);
+        if (up >= 16 && bgzf_inflate_range(file.p, head, 0, head.size(), buf.data(), 1) == EPI_OK && memcmp(buf.data(), "BAM\1", 4) == 0) {
+          size_t p = 8 + (size_t)rd32(buf.data() + 4);
+          uint64_t nref = p + 4 <= up ? rd32(buf.data() + p) : 0;
+          p += 4;
+          while (nref > 0 && p + 4 <= up) { p += 8 + (size_t)rd32(buf.data() + p); nref--; }
+          uint64_t bytes = 0, bases = 0;
+          while (nref == 0 && p + 36 <= up) {
+            const size_t bs = rd32(buf.data() + p);
+            if (bs < 32 || p + 4 + bs > up) break;
+            bytes += 4 + bs; bases += rd32(buf.data() + p + 4 + 16);
+            p += 4 + bs;
+          }
+          if (bytes >= 4096 && bases > 0 && bases < bytes) ratio = (double)bases / (double)bytes;
+        }
+      }
+      pin.cap = ((size_t)((double)total * ratio * 1.15) + ((size_t)1 << 20) + 15) / 16 * 16;
+      int cur_dev = -1;                                      // the caller's device, not device 0: every rank of a multi-GPU job pins under its own GPU
+      if (hipGetDevice(&cur_dev) != hipSuccess) { (void)hipGetLastError(); cur_dev = -1; }
+      pin.th = std::thread([&pin, cur_dev]() {
         int ndev = 0;
-        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&pin.p, pin.cap, hipHostMallocDefault) == hipSuccess) pin.ok = true;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && (cur_dev < 0 || hipSetDevice(cur_dev) == hipSuccess) &&
+            hipHostMalloc(&pin.p, pin.cap, hipHostMallocDefault) == hipSuccess) pin.ok = true;
         else (void)hipGetLastError();
       });
     }
@@ -1023,7 +1050,9 @@ static int preprocess_impl(const char *path, const epi_bam_options *opt_in, epi_
   xmp = malloc(cap); out->pinned = 0;                      // host-only sanitizer build (`make asan`)
 #else
   pin.wait();
-  if (pin.ok && pin.cap >= cap) {                          // the buffer pinned while the file was being read
+  // the buffer pinned while the file was being read -- unless it turned out too small, or more than a quarter larger
+  // than needed (page-locked memory stays pinned for the life of the templates: then the exact size is allocated)
+  if (pin.ok && pin.cap >= cap && pin.cap <= cap + cap / 4 + ((size_t)4 << 20)) {
     xmp = pin.p; cap = pin.cap; out->pinned = 1;
     pin.p = nullptr; pin.ok = false;
   } else {

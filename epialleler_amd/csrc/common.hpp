@@ -133,6 +133,7 @@ struct epi_batch {
   uint32_t mhl_slot = 0, mhl_last_slot = 0, mhl_last_ovf = 0;   // the same for the lMHL report
   uint32_t mhlf_slot = 0;                      // ... and its fused kernel (1024-position tiles)
   bool mhlf_prefer_wide = false;               // most tiles of the last fused lMHL report needed the u64 sums: start with that variant
+  uint32_t mhlf_prefer_wide_H = 0;             // ... learned for this haplotype clamp H (the sums shrink with H: a smaller one probes the fast variant again)
   bool mhlf_prefer_fold = false;               // ... many held more than 255 rows: use the kernel with the folded call counters
   epi::DevBuf mhlf_fold_slab;                  // call counters of tiles over 255 rows (kernels built without the LDS fold array)
   bool mhl_shared_fused = false;               // the lMHL slabs attached are in the fused kernel's layout (mhl_common.hpp)

@@ -1350,7 +1350,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     }
   }
   if (nt == 0 || np == 0) {                                // no rows, or a context string without H/X/Z: an empty table
-    b->last_kind = 1; b->last_nrow = 0; b->last_ntiles = 0;
+    // (a rank of a sharded run without rows still takes part in the exchange: its second half returns the empty table)
+    b->last_kind = !b->shared_keys.empty() && b->d_slab ? 3 : 1; b->last_nrow = 0; b->last_ntiles = 0;
     return EPI_OK;
   }
 
@@ -1551,6 +1552,7 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   EPI_HIP(hipSetDevice(b->eng->device));
   hipStream_t s = pick_stream(b, stream);
   const int32_t nt = b->last_ntiles;
+  if (nt == 0) { b->last_kind = 1; b->last_nrow = 0; *nrow_out = 0; return EPI_OK; }   // this rank holds no rows: owns no tile
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
   Cx2Args a;
   memset(&a, 0, sizeof(a));

@@ -1035,7 +1035,10 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     a.tile_list = nullptr;
     const unsigned grid = (unsigned)(((nt + 7) / 8) * 8);
     prof_begin("mhl_tiles", s);
-    if (b->mhlf_prefer_wide) launch_mhl_fused<true>(gc, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a, fold);
+    // (the preference was learned for one H: S(min(h, H)) shrinks with H, so a report with a smaller H starts on the fast
+    //  variant again, which lists the tiles that still need the wide sums)
+    const bool wide_first = b->mhlf_prefer_wide && H >= b->mhlf_prefer_wide_H;
+    if (wide_first) launch_mhl_fused<true>(gc, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a, fold);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -1057,8 +1060,10 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
       EPI_TRY(read_scalars(b, s, cursor, 8, again));
       host4[1] = again[0]; host4[2] = again[1];
       b->mhlf_prefer_wide = host4[3] > (uint32_t)nt / 2;   // most tiles needed the wide sums: start there next time
+      b->mhlf_prefer_wide_H = H;
     }
     if (!fold && host4[5] > fold_slots / 2) b->mhlf_prefer_fold = true;   // many tiles over 255 rows: LDS fold array next time
+    // (rows per tile are a property of the immutable batch, not of the report's parameters: this one may stay)
     host[0] = host4[1]; host[1] = host4[2]; host[2] = host4[3];
 #ifdef EPI_CHECK
     {

@@ -1001,7 +1001,10 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   int32_t nt = 0;
   EPI_TRY(build_tiles(b, s, kMhlTile, &st, &nt));
   b->last_ntiles = nt;
-  if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; return EPI_OK; }
+  if (nt == 0) {                                           // (a rank of a sharded run without rows still takes part in the exchange)
+    b->last_kind = !b->shared_keys.empty() && b->d_mhl_cnt_slab ? 4 : 2; b->last_nrow = 0;
+    return EPI_OK;
+  }
 
   // pass 1 workspace: per-read info, record table, records (grown on demand like the row pool)
   const int gc = pick_mhl_group(st.max_len);
@@ -1244,6 +1247,7 @@ int epi_batch_mhl_finish_shared(epi_batch *b, void *stream, int64_t *nrow_out) {
   hipStream_t s = pick_stream(b, stream);
   if (b->last_kind == 5) return mhl_fused_finish_shared(b, s, nrow_out);   // the one-pass kernel's slabs
   const int32_t nt = b->last_ntiles;
+  if (nt == 0) { b->last_kind = 2; b->last_nrow = 0; *nrow_out = 0; return EPI_OK; }   // this rank holds no rows: owns no tile
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
   MhlArgs a;
   memset(&a, 0, sizeof(a));

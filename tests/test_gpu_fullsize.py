@@ -6,45 +6,19 @@ import pytest
 
 import helpers as H
 from oracle import oracle as orc
+from oracle import windows as W
 
 pytestmark = pytest.mark.gpu
 
 
 def _window_rows(bam, lo, hi):
     """Host copy of rows [lo,hi) of a device-resident batch."""
-    d = bam.dev
-    off = d["off"][lo:hi + 1].cpu().numpy()
-    xm = d["xm"][int(off[0]):int(off[-1])].cpu().numpy()
-    return {"xm": xm, "off": off - off[0], "rname": d["rname"][lo:hi].cpu().numpy(),
-            "strand": d["strand"][lo:hi].cpu().numpy(), "start": d["start"][lo:hi].cpu().numpy()}
+    return W.window_rows(bam.dev, lo, hi)
 
 
 def _check_windows(rep, bam, n, oracle_fn, float_cols=(), L=300, wrows=20000, starts=None):
-    key = rep["rname"].astype(np.int64) * (1 << 33) + rep["pos"].astype(np.int64) * 2 + (rep["strand"] - 1)
-    assert np.all(np.diff(key) > 0)                     # reference row order, no duplicates
-    del key
-    for lo in (starts or (0, n // 3 + 17, n - wrows)):  # includes both ends and a chromosome interior
-        hi = lo + wrows
-        w = _window_rows(bam, lo, hi)
-        want = oracle_fn(w)
-        # rows of the window are complete only where no read outside [lo,hi) can reach: trim one read length
-        r0 = int(w["rname"][0])
-        p_lo = int(w["start"][0]) + L if lo > 0 else -1
-        r1 = int(w["rname"][-1])
-        p_hi = int(w["start"][-1]) - 1 if hi < n else 2 ** 31
-        def inner(t):
-            k = (t["rname"].astype(np.int64) << 32) + t["pos"]
-            return (k >= ((r0 << 32) + p_lo)) & (k <= ((r1 << 32) + p_hi))
-        mw = inner(want)
-        mg = inner(rep)
-        assert mw.sum() > 300
-        for c in want:
-            a, b = rep[c][mg], want[c][mw]
-            assert a.shape == b.shape, c
-            if c in float_cols:
-                assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), c
-            else:
-                assert np.array_equal(a, b), c
+    """Strict row order of the whole table + exact agreement with the oracle on row windows (oracle/windows.py)."""
+    return W.check_windows(rep, bam.dev, n, oracle_fn, float_cols=float_cols, L=L, wrows=wrows, starts=starts)
 
 
 def test_config2_cytosine_report_10M():
@@ -174,4 +148,65 @@ def test_uniform_stream_cytosine_report():
     m = ea.generateMhlReport(bam)
     _check_windows(m, bam, n, lambda w: orc.mhl_report(w["xm"], w["off"], w["rname"], w["strand"], w["start"], "Zz", 0, 0, 0.1),
                    float_cols=("length", "lmhl"), L=360)
+    bam.close()
+
+
+# ---- the streams bench.py times (SURVEY 8d's literal wording: uniform-random starts sorted on the device, fixed L) --------
+
+def _uniform(n, L, seed=42, **kw):
+    from epialleler_amd import synth
+    return synth.generate_device_uniform(n_total=n, mean_len=L, seed=seed, ragged=False, gap_every=0, **kw)
+
+
+def test_bench_cfg2_stream_10M():
+    """bench.py's headline batch itself (cfg2: seed 42, 10 M templates, L = 300, 4 chromosomes): thresholded CG report,
+    un-thresholded CG and CX reports (cfg2n / cfg2cx) against the oracle on windows."""
+    import epialleler_amd as ea
+    n = 10_000_000
+    bam = _uniform(n, 300)
+    rep = ea.generateCytosineReport(bam, threshold_reads=True, as_device=True)
+    assert 5_000_000 < rep.nrow < 9_000_000
+    _check_windows(rep, bam, n, W.oracle_for("cx", True, "Z"))
+    del rep
+    rep = ea.generateCytosineReport(bam, threshold_reads=False, as_device=True)
+    _check_windows(rep, bam, n, W.oracle_for("cx", False, "Z"))
+    del rep
+    rep = ea.generateCytosineReport(bam, threshold_reads=False, report_context="CX", as_device=True)
+    _check_windows(rep, bam, n, W.oracle_for("cx", False, "ZXH"))
+    bam.close()
+
+
+def test_bench_cfg2_stream_three_chromosomes():
+    """The N > 1 stream of bench.py (3 chromosomes: every cut of 2 / 4 / 8 equal row ranges lies inside a chromosome), on one GPU."""
+    import epialleler_amd as ea
+    n = 10_000_000
+    bam = _uniform(n, 300, n_chr=3)
+    rep = ea.generateCytosineReport(bam, threshold_reads=True, as_device=True)
+    _check_windows(rep, bam, n, W.oracle_for("cx", True, "Z"), starts=(0, n // 3 - 10_000, 2 * n // 3 - 10_000, n - 20000))
+    bam.close()
+
+
+def test_bench_cfg4_stream_50M():
+    """bench.py's cfg4 batch (50 M templates, 15 GB): generateMhlReport defaults; windows where the byte offset crosses
+    2^32 and 2^33 and at the end of the batch."""
+    import epialleler_amd as ea
+    n = 50_000_000
+    bam = _uniform(n, 300)
+    rep = ea.generateMhlReport(bam, as_device=True)
+    _check_windows(rep, bam, n, W.oracle_for("mhl"), float_cols=("length", "lmhl"),
+                   starts=(0, 14_316_000, 28_632_500, n - 20000))
+    bam.close()
+
+
+def test_bench_cfg5_stream_full_50GB():
+    """bench.py's cfg5 batch at its full size: 5 M templates of 10 kb = 50 GB of xm, byte offsets beyond 2^35; the
+    un-thresholded CG report against the oracle on windows at the start, behind 2^32 / 2^34 / 2^35 bytes and at the end."""
+    import epialleler_amd as ea
+    n = 5_000_000
+    bam = _uniform(n, 10000)
+    assert bam.nbytes > 2 ** 35
+    rep = ea.generateCytosineReport(bam, threshold_reads=False, as_device=True)
+    res = _check_windows(rep, bam, n, W.oracle_for("cx", False, "Z"), L=10000, wrows=1500,
+                         starts=(0, 429_500, 1_718_000, 3_440_000, n - 1500))
+    assert res["windows"][3]["byte_offset"] > 2 ** 35
     bam.close()

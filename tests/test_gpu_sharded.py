@@ -27,7 +27,9 @@ def _free_port():
 
 def _case(name):
     rng = np.random.default_rng(77)
-    if name == "wgs":
+    if name in ("wgs", "wgs_empty", "amplicon_empty"):
+        if name == "amplicon_empty":
+            return synth_np.random_templates(rng, 4000, 100, 400, 1, 30)
         return synth_np.generate(n_total=9000, read_len=300, n_chr=3)
     if name == "amplicon":
         return synth_np.random_templates(rng, 4000, 100, 400, 1, 30)
@@ -49,6 +51,9 @@ def _worker(rank, world, port, name, outdir):
     t = _case(name)
     n = t["off"].size - 1
     lo, hi = n * rank // world, n * (rank + 1) // world
+    if name.endswith("_empty"):                             # the last rank holds no rows at all (it still takes part in the exchange)
+        w1 = world - 1
+        lo, hi = (n * rank // w1, n * (rank + 1) // w1) if rank < w1 else (n, n)
     off = t["off"][lo:hi + 1]
     shard = ea.ProcessedBam.from_arrays(t["xm"][int(off[0]):int(off[-1])], off - off[0], t["rname"][lo:hi],
                                         t["strand"][lo:hi], t["start"][lo:hi])
@@ -65,7 +70,7 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name", [(2, "wgs"), (3, "amplicon"), (2, "mixed")])
+@pytest.mark.parametrize("world,name", [(2, "wgs"), (3, "amplicon"), (2, "mixed"), (3, "wgs_empty"), (3, "amplicon_empty")])
 def test_sharded_equals_oracle(tmp_path, world, name):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
