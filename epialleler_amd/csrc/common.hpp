@@ -204,6 +204,7 @@ struct Options {
   int device = 0;            // EPIHIP_DEVICE        device of the default engine (host-pointer entry points)
   int cx_slot = -1;          // EPIHIP_CX_SLOT       pool rows per tile slot of the CX report (-1: adaptive)
   int cx_lean = 1;           // EPIHIP_CX_LEAN=0     the general (u16-folding) CX kernel for every tile
+  int cx_walk = 0;           // EPIHIP_CX_WALK=K     timing builds with -DEPI_CX_WALK_BUILD only: K consecutive tiles per workgroup of the lean CX kernel
   int heavy_rows = 0;        // EPIHIP_HEAVY_ROWS    candidate rows above which a tile is split / set aside (0: default)
   int tile_hint = 1;         // EPIHIP_TILE_HINT=0   tile index counted and scanned by every call
   int mhl_fused = 1;         // EPIHIP_MHL_FUSED=0   two-kernel lMHL path for every batch

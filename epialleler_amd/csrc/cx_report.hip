@@ -106,19 +106,28 @@ struct Cx2Args {
   const uint32_t *tile_list, *tile_list_count;   // general kernel behind a lean one: the list to work through
   uint32_t *dbg;                          // check build only (EPI_CHECK): first index violation; null in the product
   int64_t nrows;                          // rows of the batch (check build)
+  int walk;                               // walking lean kernel: consecutive tiles per workgroup
 };
 
 // LEAN: no position of the batch is covered by more than 255 rows (RowStats::deep == 0, tiles.hip), so the u8 counters
 // cannot overflow however many rows a tile has: no u16 copy, no folds, the emit reads the u8 counters.
-template <int T, int NP, bool LEAN = false> struct Cx2Lds {
-  static constexpr int Q = T / 4;
+// PAD > 0 (a WALKING workgroup, lean kernel only): the arrays hold W = T + PAD positions -- the tile and the reach of its
+// own rows into the next tile.  The workgroup works through consecutive tiles; after a tile's emit the PAD positions
+// behind it are shifted to the front and become the next tile's opening state, so that a row is analysed ONCE, by the
+// tile it starts in (without it 15 % of the PE150 row visits of a 2048-position tile are second visits of rows that
+// reach into the next tile: each a full load + thresholding decision).
+template <int T, int NP, bool LEAN = false, int PAD = 0> struct Cx2Lds {
+  static_assert(PAD == 0 || (LEAN && PAD % 16 == 0 && PAD <= T), "the window is a lean-kernel feature");
+  static constexpr int TILE = T, W = T + PAD;    // positions of the tile / held in LDS
+  static constexpr int Q = W / 4;
   static constexpr int N_NARROW = 2 * NP * Q;    // u64: [strand][plane][Q], low dword = n of 4 positions (u8), high = M
   static constexpr int N_CORR = 2 * Q;           // u64: [strand][Q], low dword = skipped, high = doubled (u8 x 4)
   static constexpr int N_WIDE = LEAN ? 16 : 2 * NP * T;   // u32: [strand][plane][T] = n | M << 16 (LEAN: scan scratch only)
-  static constexpr int N_COV = T;                // u32: coverage difference array, '+' in the low half, '-' in the high half
-                                                 // (a change "behind the tile" is simply not recorded)
+  static constexpr int N_COV = W;                // u32: coverage difference array, '+' in the low half, '-' in the high half
+                                                 // (a change "behind the window" is simply not recorded)
   unsigned long long *narrow, *corr;
   uint32_t *wide, *cov;
+  uint32_t tid;                                  // threadIdx.x (a walking workgroup reads it anew for every tile, see k_cx_tiles)
 };
 
 // 16-entry byte LUT lookup of the four codes of a dword in two v_perm_b32 (X: the table in lut16_xor_form, common.hpp);
@@ -224,7 +233,7 @@ __device__ __forceinline__ void cx2_mask_upto(int hi /* 1..16 */, uint32_t (&m)[
 template <int T, int G, int NU, int NP, bool FUSED, class LT, class F>
 __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t cs, int32_t cz, int sub, int rcur,
                                           const LT &L, F fetch_next) {
-  constexpr int C = T / CX_CH, Q = T / 4;
+  constexpr int C = LT::W / CX_CH, Q = LT::Q;                       // chunks / u64 cells per strand of the window (= the tile unless the workgroup walks)
   const int32_t cb = cs + sub;                                      // this lane's chunks: cb + u*G
   const int32_t tl = cz - cb;                                       // chunk u is part of the visit iff u*G <= tl
   uint32_t w[NU][4];
@@ -405,15 +414,25 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
 // wavefront step); the next step's row columns are fetched while the current row's bytes are in flight.
 template <int T, int G, int NU, int NP, bool FUSED, int WG, class LT>
 __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const LT &L) {
-  constexpr int R = 64 / G, NW = WG / 64, C = T / CX_CH;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int R = 64 / G, NW = WG / 64, C = LT::W / CX_CH, TW = LT::W;
+  const int lane = L.tid & 63, wave = L.tid >> 6;
   const int sub = lane & (G - 1), grp = lane / G;
   Tile tb = td;
   tb.row_hi = row_hi;
   int r = row_lo + wave * R + grp;
   RowVals v = cx_load_row(a.c, tb, r);
+#ifdef EPI_CX_TOUCH
+  // Timing builds: one dword per 128-byte line of the row this lane group will work on TWO steps from now is requested
+  // (and dropped) a step ahead of its columns: the bytes are on their way from HBM into the L2 while the step in between
+  // is worked on.  Rows lie back to back in xm, so the row two steps ahead starts about as far behind the next step's row
+  // as that one behind the current row.
+  uint32_t touched = 0;
+#endif
   for (int rbase = row_lo + wave * R; rbase < row_hi; rbase += NW * R) {
     const int rcur = r;
+#ifdef EPI_CX_TOUCH
+    const int64_t o_cur = v.o;
+#endif
     if (!EPI_DEV_CHECK(a.dbg, !v.ok || (rcur >= 0 && rcur < a.nrows && v.len >= 0 && (v.sd == 1 || v.sd == 2 || v.len == 0)), 22, rcur, v.sd)) return;
     r += NW * R;
     RowVals nv;
@@ -441,24 +460,36 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
         }
       }
       if (sub == 0) {                                                 // coverage: +1 on the row's positions inside the tile
-        const int32_t ca = g.rel > 0 ? g.rel : 0, cb = g.rel + v.len < T ? g.rel + v.len : T;
+        const int32_t ca = g.rel > 0 ? g.rel : 0, cb = g.rel + v.len < TW ? g.rel + v.len : TW;
         const uint32_t unit = g.sidx ? 65536u : 1u;
-        if (ca < cb && !(EPI_CX_ABLATE & 32)) { atomicAdd(L.cov + ca, unit); if (cb < T) atomicAdd(L.cov + cb, 0u - unit); }
+        if (ca < cb && !(EPI_CX_ABLATE & 32)) { atomicAdd(L.cov + ca, unit); if (cb < TW) atomicAdd(L.cov + cb, 0u - unit); }
       }
     } else if (FUSED && v.ok && sub == 0 && a.pass_out && (uint32_t)((uint32_t)v.st - (uint32_t)td.pos0) < (uint32_t)T) {
       a.pass_out[rcur] = 0;             // an empty read has no call of the context: fails (rcpp_threshold_reads.cpp:43)
     }
     fetch_next();
     v = nv;
+#ifdef EPI_CX_TOUCH
+    asm volatile("" :: "v"(touched));                       // (the previous request has come back by now; its value is of no interest)
+    {
+      int64_t t = v.o + (v.o - o_cur) + 128 * sub;
+      if (!v.ok || t < 0) t = 0;
+      if (t > a.xm_cap - 4) t = a.xm_cap - 4;
+      touched = *reinterpret_cast<const uint32_t *>(a.c.xm + (t & ~(int64_t)3));
+    }
+#endif
   }
+#ifdef EPI_CX_TOUCH
+  asm volatile("" :: "v"(touched));
+#endif
 }
 
 // u8 counters -> u16 pairs, skipped / doubled codes -> coverage difference array.  Every cell has one owner thread.
-template <int T, int NP, bool LEAN, int WG>
-__device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
-  constexpr int Q = T / 4;
+template <int T, int NP, bool LEAN, int WG, int PAD = 0>
+__device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN, PAD> &L) {
+  constexpr int Q = Cx2Lds<T, NP, LEAN, PAD>::Q, TW = Cx2Lds<T, NP, LEAN, PAD>::W;
   if constexpr (!LEAN) {
-    for (int i = threadIdx.x; i < 2 * NP * Q; i += WG) {
+    for (int i = L.tid; i < 2 * NP * Q; i += WG) {
       const unsigned long long v = L.narrow[i];
       if (v == 0ull) continue;
       L.narrow[i] = 0ull;
@@ -473,7 +504,7 @@ __device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
       *wd = c;
     }
   }
-  for (int i = threadIdx.x; i < 2 * Q; i += WG) {
+  for (int i = L.tid; i < 2 * Q; i += WG) {
     const unsigned long long v = L.corr[i];
     if (v == 0ull) continue;
     L.corr[i] = 0ull;
@@ -487,7 +518,7 @@ __device__ __forceinline__ void cx2_flush(const Cx2Lds<T, NP, LEAN> &L) {
       if (d != prev) atomicAdd(L.cov + 4 * q + j, (uint32_t)((d - prev) * unit));
       prev = d;
     }
-    if (prev != 0 && 4 * q + 4 < T) atomicAdd(L.cov + 4 * q + 4, (uint32_t)(-prev * unit));
+    if (prev != 0 && 4 * q + 4 < TW) atomicAdd(L.cov + 4 * q + 4, (uint32_t)(-prev * unit));
   }
 }
 
@@ -517,14 +548,14 @@ template <int T, int NP> struct CxSrcLds {
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
 };
 // ... the u8 counters themselves (LEAN, one context) ...
-template <int T> struct CxSrcU8 {
+template <int QS> struct CxSrcU8 {         // QS = u64 cells per strand
   const uint32_t *narrow;                 // the u64 cells as dword pairs: [2 * cell] = n, [2 * cell + 1] = M of 4 positions
   const uint32_t *cov;                    // prefix-summed
   __device__ __forceinline__ uint32_t any(int sd, int pos) const {
-    return (narrow[2 * (sd * (T / 4) + (pos >> 2))] >> (8 * (pos & 3))) & 255u;
+    return (narrow[2 * (sd * QS + (pos >> 2))] >> (8 * (pos & 3))) & 255u;
   }
   __device__ __forceinline__ void pair(int sd, int, int pos, uint32_t *n, uint32_t *M) const {
-    const uint2 c = *reinterpret_cast<const uint2 *>(narrow + 2 * (sd * (T / 4) + (pos >> 2)));
+    const uint2 c = *reinterpret_cast<const uint2 *>(narrow + 2 * (sd * QS + (pos >> 2)));
     *n = (c.x >> (8 * (pos & 3))) & 255u; *M = (c.y >> (8 * (pos & 3))) & 255u;
   }
   __device__ __forceinline__ uint32_t coverage(int sd, int pos) const { const uint32_t v = cov[pos]; return sd ? v >> 16 : v & 0xFFFFu; }
@@ -547,13 +578,13 @@ template <int T, int NP> struct CxSrcSlab {
 
 // in-place inclusive prefix sum of arr[0..T) by the whole workgroup (T / WG consecutive entries per thread)
 template <int T, int WG = CX_WG>
-__device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
+__device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan, uint32_t tid = threadIdx.x) {
   constexpr int PPT = T / WG, NW = WG / 64;
   static_assert(PPT >= 1 && PPT <= 8, "prefix layout");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   uint32_t x[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; j++) x[j] = arr[threadIdx.x * PPT + j];
+  for (int j = 0; j < PPT; j++) x[j] = arr[tid * PPT + j];
 #pragma unroll
   for (int j = 1; j < PPT; j++) x[j] += x[j - 1];
   const uint32_t inc = wave_scan_u32(x[PPT - 1]);
@@ -563,7 +594,7 @@ __device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
 #pragma unroll
   for (int w = 0; w < NW; w++) before += w < wave ? s_scan[w] : 0u;
 #pragma unroll
-  for (int j = 0; j < PPT; j++) arr[threadIdx.x * PPT + j] = x[j] + before;
+  for (int j = 0; j < PPT; j++) arr[tid * PPT + j] = x[j] + before;
   __syncthreads();
 }
 
@@ -572,10 +603,10 @@ __device__ __forceinline__ void cx2_prefix(uint32_t *arr, uint32_t *s_scan) {
 // the cells with any call of a reported context (a row needs n_k > cov/2 >= 0); pass 2 reads the candidates densely,
 // one per lane, and applies the rule.  Ranks come from ballots and popcounts.
 template <int T, int NP, int WG = CX_WG, class SRC>
-__device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &src, uint32_t *s_scan, uint16_t *s_list) {
+__device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &src, uint32_t *s_scan, uint16_t *s_list, uint32_t tid = threadIdx.x) {
   constexpr int NW = WG / 64, PW = T / NW, IT = PW / 32;
   static_assert(PW % 32 == 0 && IT >= 1 && IT <= 16, "emit phase layout");   // IT = 4 (T = 1024) or 8 (2048)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int l5 = lane & 31, sd = lane >> 5;
   const uint32_t below = (1u << l5) - 1u;
   uint16_t *list = s_list + wave * (2 * PW);
@@ -623,7 +654,7 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
   }
   if (lane == 0) s_scan[wave] = carry;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     uint32_t acc = 0;
     for (int w = 0; w < NW; w++) { const uint32_t t = s_scan[w]; s_scan[w] = acc; acc += t; }
     s_scan[NW] = acc;
@@ -654,16 +685,17 @@ __device__ __forceinline__ void cx2_emit(const Cx2Args &a, int tile, const SRC &
 
 // Adds a tile's (folded) LDS sums into its dense slab [16][T] in HBM (shared tiles, heavy tiles).  The coverage
 // array goes over un-summed: difference arrays add across work items and ranks like everything else.
-template <int T, int NP, bool LEAN, int WG>
-__device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int32_t *slab) {
+template <int T, int NP, bool LEAN, int WG, int PAD = 0>
+__device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN, PAD> &L, int32_t *slab) {
   uint32_t *dst = reinterpret_cast<uint32_t *>(slab);
   if constexpr (LEAN) {
-    constexpr int Q = T / 4;
-    for (int i = threadIdx.x; i < 2 * NP * Q; i += WG) {
+    constexpr int Q = Cx2Lds<T, NP, LEAN, PAD>::Q;
+    for (int i = L.tid; i < 2 * NP * Q; i += WG) {
       const unsigned long long v = L.narrow[i];
       if (v == 0ull) continue;
       const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
       const int sp = i / Q, q = i - sp * Q;
+      if (PAD > 0 && q >= T / 4) continue;                 // (behind the tile: the next tile's share of a walking workgroup's window)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t n = (lo >> (8 * j)) & 255u, M = (hi >> (8 * j)) & 255u;
@@ -672,7 +704,7 @@ __device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int3
       }
     }
   } else {
-    for (int i = threadIdx.x; i < 2 * NP * T; i += WG) {
+    for (int i = L.tid; i < 2 * NP * T; i += WG) {
       const uint32_t v = L.wide[i];
       if (!v) continue;
       const int sp = i / T, p = i - sp * T;
@@ -680,7 +712,7 @@ __device__ __forceinline__ void cx2_dump_slab(const Cx2Lds<T, NP, LEAN> &L, int3
       if (v >> 16) atomicAdd(dst + (2 * sp + 1) * T + p, v >> 16);
     }
   }
-  for (int p = threadIdx.x; p < T; p += WG) {
+  for (int p = L.tid; p < T; p += WG) {
     const uint32_t v = L.cov[p];
     if (!v) continue;
     const int32_t lo = (int32_t)(int16_t)(v & 0xFFFFu);                // both halves are signed before the prefix sum
@@ -700,14 +732,15 @@ __device__ __forceinline__ int cx_tile_of_block(int b, int ntiles) {
 }
 
 // workgroups per CU by LDS (the u8 arrays double as the emit phase's candidate lists) and the 2048-thread limit
-template <int T, int NP, bool LEAN = false> constexpr int cx2_lds_bytes() {
-  return (Cx2Lds<T, NP, LEAN>::N_NARROW + Cx2Lds<T, NP, LEAN>::N_CORR) * 8 + (Cx2Lds<T, NP, LEAN>::N_WIDE + Cx2Lds<T, NP, LEAN>::N_COV) * 4;
+template <int T, int NP, bool LEAN = false, int PAD = 0> constexpr int cx2_lds_bytes() {
+  using LdsT = Cx2Lds<T, NP, LEAN, PAD>;
+  return (LdsT::N_NARROW + LdsT::N_CORR) * 8 + (LdsT::N_WIDE + LdsT::N_COV) * 4;
 }
 #ifndef EPI_CX_WPS
 #define EPI_CX_WPS 8
 #endif
-template <int T, int NP, int NU = 3, bool LEAN = false, int WG = CX_WG> constexpr int cx2_waves_per_simd() {
-  const int by_lds = (160 * 1024) / cx2_lds_bytes<T, NP, LEAN>(), by_thr = 2048 / WG;
+template <int T, int NP, int NU = 3, bool LEAN = false, int WG = CX_WG, int PAD = 0> constexpr int cx2_waves_per_simd() {
+  const int by_lds = (160 * 1024) / (cx2_lds_bytes<T, NP, LEAN, PAD>() + 64), by_thr = 2048 / WG;
   int wgs = by_lds < by_thr ? by_lds : by_thr;
   if (NU >= 4 && wgs * WG > 1536) wgs = 1536 / WG;        // five chunks per lane in flight need ~80 VGPRs: 6 waves per SIMD
   if (wgs * WG / 256 > EPI_CX_WPS) wgs = EPI_CX_WPS * 256 / WG;
@@ -716,8 +749,8 @@ template <int T, int NP, int NU = 3, bool LEAN = false, int WG = CX_WG> constexp
 
 // LDS of a tile workgroup.  The emit phase's candidate lists (4 T bytes) and scan scratch reuse arrays that are dead by
 // then: the u8 counters and `corr` (general kernel), or `corr` and the small `wide` stub (LEAN: the counters are read).
-#define CX2_SHARED(T, NP, LEAN)                                                                                  \
-  using LdsT = Cx2Lds<T, NP, LEAN>;                                                                              \
+#define CX2_SHARED(T, NP, LEAN, PAD)                                                                             \
+  using LdsT = Cx2Lds<T, NP, LEAN, PAD>;                                                                         \
   __shared__ __attribute__((aligned(16))) unsigned long long s_u8[LdsT::N_NARROW + LdsT::N_CORR];                \
   __shared__ __attribute__((aligned(16))) uint32_t s_wide[LdsT::N_WIDE];                                         \
   __shared__ __attribute__((aligned(16))) uint32_t s_cov[LdsT::N_COV];                                           \
@@ -726,24 +759,24 @@ template <int T, int NP, int NU = 3, bool LEAN = false, int WG = CX_WG> constexp
   uint16_t *s_list = reinterpret_cast<uint16_t *>(LEAN ? s_u8 + LdsT::N_NARROW : s_u8);                          \
   (void)s_scan; (void)s_list;                                                                                     \
   LdsT L;                                                                                                         \
-  L.narrow = s_u8; L.corr = s_u8 + LdsT::N_NARROW; L.wide = s_wide; L.cov = s_cov;
+  L.narrow = s_u8; L.corr = s_u8 + LdsT::N_NARROW; L.wide = s_wide; L.cov = s_cov; L.tid = threadIdx.x;
 
-template <int T, int NP, bool LEAN, int WG>
-__device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP, LEAN> &L) {
-  using LdsT = Cx2Lds<T, NP, LEAN>;
+template <int T, int NP, bool LEAN, int WG, int PAD = 0>
+__device__ __forceinline__ void cx2_clear(const Cx2Lds<T, NP, LEAN, PAD> &L) {
+  using LdsT = Cx2Lds<T, NP, LEAN, PAD>;
   uint4 *z = reinterpret_cast<uint4 *>(L.narrow);
-  for (int i = threadIdx.x; i < (LdsT::N_NARROW + LdsT::N_CORR) / 2; i += WG) z[i] = make_uint4(0, 0, 0, 0);
+  for (int i = L.tid; i < (LdsT::N_NARROW + LdsT::N_CORR) / 2; i += WG) z[i] = make_uint4(0, 0, 0, 0);
   if constexpr (!LEAN) {
     uint4 *y = reinterpret_cast<uint4 *>(L.wide);
-    for (int i = threadIdx.x; i < LdsT::N_WIDE / 4; i += WG) y[i] = make_uint4(0, 0, 0, 0);
+    for (int i = L.tid; i < LdsT::N_WIDE / 4; i += WG) y[i] = make_uint4(0, 0, 0, 0);
   }
   uint4 *x = reinterpret_cast<uint4 *>(L.cov);
-  for (int i = threadIdx.x; i < LdsT::N_COV / 4; i += WG) x[i] = make_uint4(0, 0, 0, 0);
+  for (int i = L.tid; i < LdsT::N_COV / 4; i += WG) x[i] = make_uint4(0, 0, 0, 0);
 }
 
 // rows [row_lo, row_hi) of a tile, folded every CX_FLUSH_ROWS rows; leaves everything in `wide` and `cov`
-template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, int WG>
-__device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP, LEAN> &L) {
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, int WG, int PAD = 0>
+__device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td, int row_lo, int row_hi, const Cx2Lds<T, NP, LEAN, PAD> &L) {
   if constexpr (LEAN) {
     cx2_rows<T, G, NU, NP, FUSED, WG>(a, td, row_lo, row_hi, L);
   } else {
@@ -753,7 +786,7 @@ __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td,
     }
   }
   __syncthreads();
-  cx2_flush<T, NP, LEAN, WG>(L);
+  cx2_flush<T, NP, LEAN, WG, PAD>(L);
   __syncthreads();
 }
 
@@ -761,89 +794,183 @@ __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td,
 //  work per tile weighs half as much, and 80 VGPRs for the five-chunk lane shapes)
 template <bool LEAN> constexpr int cx2_wg() { return LEAN ? 256 : CX_WG; }
 
-// One tile: accumulate, then hand over (heavy / shared / deep tiles) or emit.
-template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, class LdsT>
-__device__ __forceinline__ void cx2_tile(const Cx2Args &a, int tile, const LdsT &L, uint32_t *s_scan, uint16_t *s_list, int *s_flag) {
+// A walking workgroup's step from one tile to the next: the PAD positions behind the tile become the front of the window.
+// `narrow` moves as it is; `cov` -- prefix-summed in place over the tile by now -- hands on its running sum (the coverage
+// entering the next tile) in the new first entry, followed by the un-summed differences behind the tile; `corr` was folded
+// into `cov` by the flush and then used as the emit's candidate list: cleared.  Values travel through registers between
+// two barriers (source and destination ranges of different threads overlap).
+template <int T, int NP, int WG, int PAD>
+__device__ __forceinline__ void cx2_shift(const Cx2Lds<T, NP, true, PAD> &L) {
+  using LdsT = Cx2Lds<T, NP, true, PAD>;
+  constexpr int Q = LdsT::Q, QT = T / 4, QP = PAD / 4, NN = 2 * NP * QP;      // u64 cells per strand and plane: window, tile, overhang
+  constexpr int KN = (NN + WG - 1) / WG, KC = (PAD + WG - 1) / WG;
+  unsigned long long nv[KN];
+  uint32_t cv[KC];
+#pragma unroll
+  for (int k = 0; k < KN; k++) {
+    const int i = (int)L.tid + k * WG;
+    nv[k] = i < NN ? L.narrow[(i / QP) * Q + QT + (i % QP)] : 0ull;
+  }
+#pragma unroll
+  for (int k = 0; k < KC; k++) {
+    const int i = (int)L.tid + k * WG;
+    cv[k] = i < PAD ? L.cov[T + i] + (i == 0 ? L.cov[T - 1] : 0u) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KN; k++) {
+    const int i = (int)L.tid + k * WG;
+    if (i < NN) L.narrow[(i / QP) * Q + (i % QP)] = nv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < KC; k++) {
+    const int i = (int)L.tid + k * WG;
+    if (i < PAD) L.cov[i] = cv[k];
+  }
+  // everything behind the carried part starts at zero (16-byte stores: QP, QT and PAD are multiples of 4)
+  for (int i = L.tid; i < 2 * NP * (QT / 2); i += WG) {
+    const int sp = i / (QT / 2), j = i - sp * (QT / 2);
+    *reinterpret_cast<uint4 *>(L.narrow + sp * Q + QP + 2 * j) = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = L.tid; i < T / 4; i += WG) *reinterpret_cast<uint4 *>(L.cov + PAD + 4 * i) = make_uint4(0, 0, 0, 0);
+  for (int i = L.tid; i < LdsT::N_CORR / 2; i += WG) *reinterpret_cast<uint4 *>(L.corr + 2 * i) = make_uint4(0, 0, 0, 0);
+}
+
+// One tile: accumulate, then hand over (heavy / shared / deep tiles) or emit.  `fresh`: the arrays do not hold the previous
+// tile's overhang (always, unless the workgroup walks): they are cleared and every candidate row of the tile is visited;
+// otherwise only the rows that start in the tile, [row_from, row_hi).  Returns false when the tile was handed over without
+// being accumulated (a walking workgroup then has nothing to carry on).
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, int PAD, class LdsT>
+__device__ __forceinline__ bool cx2_tile(const Cx2Args &a, int tile, const Tile &td, bool fresh, int row_from, const LdsT &L, uint32_t *s_scan,
+                                         uint16_t *s_list, int *s_flag) {
   constexpr int WG = cx2_wg<LEAN>();
-  const Tile td = a.tiles[tile];                          // (in flight while the counters are cleared)
-  cx2_clear<T, NP, LEAN, WG>(L);
+  if (fresh) cx2_clear<T, NP, LEAN, WG, PAD>(L);
   if (td.row_hi - td.row_lo > a.heavy_rows) {
     // one workgroup would crawl through this pile-up alone: k_cx_heavy splits it by row chunks instead
-    if (threadIdx.x == 0) {
+    if (L.tid == 0) {
       const uint32_t h = atomicAdd(a.heavy_count, 1u);
       a.heavy_list[h] = (uint32_t)tile;
       atomicMax(a.heavy_max, (uint32_t)(td.row_hi - td.row_lo));
       a.tile_nrow[tile] = 0;
       a.tile_base[tile] = 0;
     }
-    return;
+    return false;
   }
   if constexpr (LEAN) {
     // u8 counters hold 255 rows per position.  Few enough candidate rows: safe.  Else the sorted starts decide: rows
     // covering a position p all start before the end of the first of them, so if row x + 255 starts at or behind the end
     // of row x for every candidate x, no position of the tile is covered by more than 255 rows (tiles.hip: k_row_stats
-    // asks the same of the whole batch).  A tile that fails goes to the general kernel's list.
+    // asks the same of the whole batch).  A tile that fails goes to the general kernel's list.  (The overhang a walking
+    // workgroup carries into the tile comes from candidate rows of the tile as well: the criterion covers it.)
     if (a.deep_list && td.row_hi - td.row_lo > CX_FLUSH_ROWS) {
-      if (threadIdx.x == 0) *s_flag = 0;
+      if (L.tid == 0) *s_flag = 0;
       __syncthreads();
       bool deep = false;
-      for (int x = td.row_lo + (int)threadIdx.x; x + CX_FLUSH_ROWS < td.row_hi; x += WG)
+      for (int x = td.row_lo + (int)L.tid; x + CX_FLUSH_ROWS < td.row_hi; x += WG)
         deep |= (int64_t)a.c.start[x + CX_FLUSH_ROWS] < (int64_t)a.c.start[x] + (a.c.off[x + 1] - a.c.off[x]);
       if (deep) *s_flag = 1;
       __syncthreads();
       if (*s_flag) {
-        if (threadIdx.x == 0) { a.deep_list[atomicAdd(a.deep_count, 1u)] = (uint32_t)tile; a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
-        return;
+        if (L.tid == 0) { a.deep_list[atomicAdd(a.deep_count, 1u)] = (uint32_t)tile; a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+        return false;
       }
     }
   }
   __syncthreads();
-  cx2_accumulate<T, G, NU, NP, FUSED, LEAN, WG>(a, td, td.row_lo, td.row_hi, L);
+  cx2_accumulate<T, G, NU, NP, FUSED, LEAN, WG, PAD>(a, td, row_from, td.row_hi, L);
   if (td.slot >= 0) {
-    // shared with another rank: hand the raw sums over
-    cx2_dump_slab<T, NP, LEAN, WG>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
-    if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
-    return;
+    // shared with another rank: hand the raw sums over (a carried-in coverage is part of the first difference)
+    cx2_dump_slab<T, NP, LEAN, WG, PAD>(L, a.slab + (int64_t)td.slot * (kCxPlanes * T));
+    if (L.tid == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; }
+    if constexpr (PAD > 0) { __syncthreads(); cx2_prefix<T, WG>(L.cov, s_scan, L.tid); }    // (the walk goes on from the summed coverage)
+    return true;
   }
-  if (EPI_CX_ABLATE & 16) { if (threadIdx.x == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return; }
+  if (EPI_CX_ABLATE & 16) { if (L.tid == 0) { a.tile_nrow[tile] = 0; a.tile_base[tile] = 0; } return true; }
   // (a list-free emit -- every thread ruling on its own 8 cells, two barriers instead of four -- measured 1-2 % slower)
-  cx2_prefix<T, WG>(L.cov, s_scan);
+  cx2_prefix<T, WG>(L.cov, s_scan, L.tid);
   if constexpr (LEAN) {
     static_assert(NP == 1, "the u8 counters serve single-context reports");
-    CxSrcU8<T> src;
+    CxSrcU8<LdsT::Q> src;
     src.narrow = reinterpret_cast<const uint32_t *>(L.narrow); src.cov = L.cov;
-    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list);
+    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list, L.tid);
   } else {
     CxSrcLds<T, NP> src;
     src.wide = L.wide; src.cov = L.cov;
-    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list);
+    cx2_emit<T, NP, WG>(a, tile, src, s_scan, s_list, L.tid);
   }
+  return true;
 }
 
-template <int T, int G, int NU, int NP, bool FUSED, bool LEAN>
-__global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN, cx2_wg<LEAN>()>())) void k_cx_tiles(Cx2Args a, int ntiles) {
-  CX2_SHARED(T, NP, LEAN)
+template <int T, int G, int NU, int NP, bool FUSED, bool LEAN, int PAD = 0>
+__global__ __launch_bounds__(cx2_wg<LEAN>(), (cx2_waves_per_simd<T, NP, NU, LEAN, cx2_wg<LEAN>(), PAD>())) void k_cx_tiles(Cx2Args a, int ntiles) {
+  CX2_SHARED(T, NP, LEAN, PAD)
   __shared__ int s_flag;
+#ifdef EPI_CX_LDS_PAD                                      // timing builds: LDS that nobody uses (workgroups per CU by LDS)
+  __shared__ uint32_t s_pad[EPI_CX_LDS_PAD / 4];
+  if (a.xm_cap == -12345) s_pad[threadIdx.x] = 1;
+#endif
   if constexpr (!LEAN) {
     if (a.tile_list) {                                    // behind a lean launch: the tiles it listed, however many (fixed grid)
       const uint32_t n = *a.tile_list_count;
       for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        cx2_tile<T, G, NU, NP, FUSED, LEAN>(a, (int)a.tile_list[i], L, s_scan, s_list, &s_flag);
+        const int tile = (int)a.tile_list[i];
+        const Tile td = a.tiles[tile];
+        cx2_tile<T, G, NU, NP, FUSED, LEAN, 0>(a, tile, td, true, td.row_lo, L, s_scan, s_list, &s_flag);
         __syncthreads();                                  // (the next tile clears the arrays the emit just read)
       }
       return;
     }
   }
-  const int tile = cx_tile_of_block(blockIdx.x, ntiles);
-  if (tile >= ntiles) return;
-  cx2_tile<T, G, NU, NP, FUSED, LEAN>(a, tile, L, s_scan, s_list, &s_flag);
+  if constexpr (PAD > 0) {
+    // A WALKING workgroup: a.walk consecutive entries of the tile table.  While the next entry is the genomic neighbour of
+    // the one just finished, its opening state is the shifted overhang and only the rows that start in it -- the rows
+    // behind the previous entry's last row -- are visited; the first tile of a walk, and one behind a gap, a change of
+    // reference sequence or a tile that was handed over (heavy, deep), starts from cleared arrays and visits all its
+    // candidate rows, like a workgroup that does not walk.
+    const int walk = a.walk;
+    const int nruns = (ntiles + walk - 1) / walk;
+    const int run = cx_tile_of_block(blockIdx.x, nruns);
+    if (run >= nruns) return;
+    const int t0 = run * walk, t1 = t0 + walk < ntiles ? t0 + walk : ntiles;
+    // (the tile table through a constant-address-space pointer: it was written by the index kernel before this one and is
+    //  read-only here, and this way a descriptor is a scalar load -- the next tile's is requested a whole tile ahead)
+    typedef const Tile __attribute__((address_space(4))) *TileK;
+    const TileK tk = (TileK)(uintptr_t)a.tiles;
+    bool carry = false;
+    int64_t prev_pos0 = 0;
+    int32_t prev_rname = 0, prev_row_hi = 0;
+    auto tile_at = [&](int i) { Tile t; t.pos0 = tk[i].pos0; t.rname = tk[i].rname; t.row_lo = tk[i].row_lo; t.row_hi = tk[i].row_hi; t.slot = tk[i].slot; return t; };
+    Tile td = tile_at(t0);
+    for (int tile = t0; tile < t1; tile++) {
+      const Tile nxt = tile_at(tile + 1 < t1 ? tile + 1 : tile);
+      // The thread index is read anew for every tile (it passes through an empty asm): everything derived from it
+      // (lane-dependent LDS addresses, list slots of the emit) is otherwise computed once in front of the loop and kept in
+      // vector registers throughout (21 of them spilled to scratch, measured; this kernel does not survive scratch)
+      { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); L.tid = t; }
+      const bool cont = carry && td.rname == prev_rname && td.pos0 == prev_pos0 + T;
+      const bool done = cx2_tile<T, G, NU, NP, FUSED, LEAN, PAD>(a, tile, td, !cont, cont ? prev_row_hi : td.row_lo, L, s_scan, s_list, &s_flag);
+      carry = done;
+      if (tile + 1 < t1) {
+        __syncthreads();                                  // (the emit has read the counters; a handed-over tile leaves them untouched)
+        if (done) { cx2_shift<T, NP, cx2_wg<LEAN>(), PAD>(L); __syncthreads(); }
+      }
+      prev_pos0 = td.pos0; prev_rname = td.rname; prev_row_hi = td.row_hi;
+      td = nxt;
+    }
+    return;
+  } else {
+    const int tile = cx_tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const Tile td = a.tiles[tile];                        // (in flight while the counters are cleared)
+    cx2_tile<T, G, NU, NP, FUSED, LEAN, 0>(a, tile, td, true, td.row_lo, L, s_scan, s_list, &s_flag);
+  }
 }
 
 // One chunk of the candidate rows of one heavy tile: LDS sums as usual, then added into the tile's slab in HBM (or
 // straight into its shared slab slot when other ranks contribute too).
 template <int T, int G, int NU, int NP, bool FUSED>
 __global__ __launch_bounds__(CX_WG, (cx2_waves_per_simd<T, NP, NU>())) void k_cx_heavy(Cx2Args a) {
-  CX2_SHARED(T, NP, false)
+  CX2_SHARED(T, NP, false, 0)
   const uint32_t hi_idx = (uint32_t)a.heavy_first + blockIdx.y;
   if (hi_idx >= *a.heavy_count) return;
   const int tile = (int)a.heavy_list[hi_idx];
@@ -1138,8 +1265,21 @@ static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_
 constexpr unsigned CX_HEAVY_CAP = 8, CX_HEAVY_GRID = 128;   // ultra-deep tiles finished without a host round trip, work items each
 constexpr unsigned CX_LIST_GRID = 512;        // workgroups of the general kernel behind a lean launch (they loop over the list)
 
+// (timing builds) A walking workgroup's window holds CX_PAD positions behind its tile: rows of up to CX_PAD - 15 bytes (a row's last
+// position-aligned chunk may end 15 positions behind its last byte), i.e. PE150 templates; four lanes per row.
+[[maybe_unused]] constexpr int CX_PAD = 320;
+
 template <int T, int NU, int NP, bool FUSED, bool LEAN>
 static void launch_cx_tiles(int g, int nt, hipStream_t s, const Cx2Args &a) {
+#ifdef EPI_CX_WALK_BUILD                                  // timing builds only (measured slower, profiles/r04_cx_experiments.txt): not in the product
+  if constexpr (LEAN && NP == 1 && NU <= 5) {
+    if (a.walk > 0 && g == 4 && !a.tile_list) {
+      const int nruns = (nt + a.walk - 1) / a.walk;
+      hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, true, CX_PAD>), dim3((unsigned)(((nruns + 7) / 8) * 8)), dim3(cx2_wg<true>()), 0, s, a, nt);
+      return;
+    }
+  }
+#endif
   const unsigned nb = a.tile_list ? CX_LIST_GRID : (unsigned)(((nt + 7) / 8) * 8);
   switch (g) {
     case 4: if constexpr (FUSED || LEAN) { hipLaunchKernelGGL((k_cx_tiles<T, 4, NU, NP, FUSED, LEAN>), dim3(nb), dim3(cx2_wg<LEAN>()), 0, s, a, nt); } break;
@@ -1391,6 +1531,15 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused, lean);
   const int grp_heavy = np > 1 ? grp : pick_cx_shape(st.max_len, T, fused, false);
 
+  // Walking workgroups (timing builds, EPI_CX_WALK_BUILD + EPIHIP_CX_WALK=K; lean kernel, rows of up to CX_PAD - 15 bytes = the
+  // four-lane shapes): every row analysed once, by the tile it starts in.  Bit-exact, but slower than one tile per
+  // workgroup at every K on config 2 (the second visits it removes are L2 hits and the kernel is bound by its memory
+  // pipeline and by the number of resident workgroups, not by row visits): profiles/r04_cx_experiments.txt.
+  a.walk = 0;
+#ifdef EPI_CX_WALK_BUILD
+  if (lean && np == 1 && (grp >> 3) == 4 && (grp & 7) <= 5 && (int64_t)st.max_len + (CX_CH - 1) <= CX_PAD && options().cx_walk > 0)
+    a.walk = options().cx_walk > 64 ? 64 : options().cx_walk;
+#endif
   a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
   a.tiles = b->tiles.as<Tile>();

@@ -35,6 +35,7 @@ static void read_options() {
   geti("EPIHIP_DEVICE", &o.device);
   geti("EPIHIP_CX_SLOT", &o.cx_slot);
   if (const char *e = getenv("EPIHIP_CX_LEAN")) o.cx_lean = atoi(e) != 0;
+  geti("EPIHIP_CX_WALK", &o.cx_walk);
   geti("EPIHIP_HEAVY_ROWS", &o.heavy_rows);
   if (o.heavy_rows < 0) o.heavy_rows = 0;
   if (const char *e = getenv("EPIHIP_TILE_HINT")) o.tile_hint = atoi(e) != 0;

@@ -25,6 +25,13 @@ def main():
     t["off"] = (np.arange(41, dtype=np.int64) * 256)
     t["strand"] = (1 + (np.arange(40) & 1)).astype(np.int32)
     sets.append(t)
+    # short reads (up to 305 bytes: the four-lane shapes of the lean CX kernel and the two-block shape of the one-pass lMHL
+    # kernel): WGS-like over three reference sequences, sparse with gaps between tiles, one 6000-row pile-up, and a pile-up
+    # inside WGS-like rows
+    sets.append(synth_np.generate(n_total=20000, read_len=300, n_chr=3))
+    sets.append(synth_np.random_templates(rng, 5000, 0, 305, 2, 120000))
+    sets.append(synth_np.random_templates(rng, 6000, 100, 300, 1, 40))
+    sets.append(synth_np.generate_uniform(n_total=12000, mean_len=300, n_chr=2, ragged=False, gap_every=0, pileup=(3000, 900)))
     for t in sets:
         bam = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"], t.get("levels"))
         try:
