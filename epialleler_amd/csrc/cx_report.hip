@@ -792,7 +792,10 @@ __device__ __forceinline__ void cx2_accumulate(const Cx2Args &a, const Tile &td,
 
 // (the lean kernel runs 256-thread workgroups, six per CU: twice the row steps per wavefront and tile, so the fixed
 //  work per tile weighs half as much, and 80 VGPRs for the five-chunk lane shapes)
-template <bool LEAN> constexpr int cx2_wg() { return LEAN ? 256 : CX_WG; }
+#ifndef EPI_CX_LEAN_WG
+#define EPI_CX_LEAN_WG 256                    // (timing builds vary it)
+#endif
+template <bool LEAN> constexpr int cx2_wg() { return LEAN ? EPI_CX_LEAN_WG : CX_WG; }
 
 // A walking workgroup's step from one tile to the next: the PAD positions behind the tile become the front of the window.
 // `narrow` moves as it is; `cov` -- prefix-summed in place over the tile by now -- hands on its running sum (the coverage
