@@ -200,6 +200,8 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
     bam = make_batch(cx, wl, rows, L, n_total, n_chr=n_chr)
     cx.torch.cuda.synchronize()
     eng = cx.D.HipShardEngine(bam) if cx.world > 1 else None
+    if eng is not None and cx.args.backend == "nccl" and not cx.args.share_gpu:
+        eng.attach_comm()                                  # RCCL behind the C ABI (one communicator per rank, created by the library)
     step = make_step(cx, wl, bam, eng, gather)
     # setup, not steps: the first calls size the engine's row pool / record space for this workload and the caching
     # allocator's blocks for the two output tables that are alive at a time (rep = step() frees the previous one late)
@@ -230,6 +232,8 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
     if keep:
         out["bam"], out["rep"], out["eng"] = bam, rep, eng
     else:
+        if eng is not None:
+            eng.close_comm()
         del rep, step, eng
         bam.close()
     return out
@@ -246,6 +250,8 @@ def selfcheck(cx, n_total):
     wl = WORKLOADS["cfg2"]
     bam = make_batch(cx, wl, rows, 300, n_total, seed=5)
     eng = D.HipShardEngine(bam)
+    if cx.args.backend == "nccl" and not cx.args.share_gpu:
+        eng.attach_comm()
     got_cx = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True, levels=bam.levels)
     xb_cx = cx.sum_over_ranks(eng.last_exchange_bytes)
     got_mhl = D.sharded_mhl(eng, gather=True, levels=bam.levels)
@@ -265,6 +271,7 @@ def selfcheck(cx, n_total):
         whole.close()
     t = torch.tensor([ok], dtype=torch.int64, device=cx.dev)
     cx.dist.broadcast(t, src=0)
+    eng.close_comm()
     bam.close()
     if int(t.item()) != 1:
         raise SystemExit("selfcheck FAILED: sharded table differs from the single-GPU table (%d rows over %d ranks)" % (n_total, cx.world))
@@ -362,38 +369,19 @@ def streamed_and_d2h(cx, wl, res):
 
 
 def sharded_one_rank(cx, wl, res, steps):
-    """N=1: what the sharded driver costs per step on top of the plain call -- the same workload through HipShardEngine
-    with 14 forced shared tiles (two per cut of an 8-GPU run) and a REAL all-reduce over a world-size-1 nccl (RCCL) group:
-    slab zeroing, tile table with slots, slab dump, the collective, the second (emit) half, both host synchronisations."""
-    import numpy as np
-    torch, D, dist = cx.torch, cx.D, cx.dist
+    """N=1: what the sharded entry point costs per step on top of the plain call -- the same workload through
+    epi_batch_cytosine_report_sharded (csrc/comm.hip: RCCL behind the C ABI) on a world-size-1 communicator with 14 forced
+    shared tiles (two per cut of an 8-GPU run): slab zeroing, tile table with slots, slab dump, a REAL ncclAllReduce of the
+    slab on the report's stream, the owners' emit, both host synchronisations.  No torch.distributed involved."""
+    torch, D = cx.torch, cx.D
     bam = res["bam"]
-    made_group = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=cx.dev)
-        made_group = True
+    eng = D.HipShardEngine(bam).attach_comm(test_shared=14)
     try:
-        eng = D.HipShardEngine(bam)
-        c = cx.ea.CONTEXT_TO_BASES["CG"]
-        ctx = cx.ea.CONTEXT_TO_BASES[wl["report_context"]]["ctx_meth"]
-        thr = (c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1) if wl["threshold"] else None
-        first, last = eng.key_range("cx", ctx)
-        mid = (first + last) // 2
-        keys = np.arange(mid, mid + 14, dtype=np.int64)     # 14 consecutive tiles inside one chromosome
-        owned = np.ones(14, dtype=np.int32)
-
-        def step():
-            if thr is not None:
-                slab = eng.cx_accumulate_fused(thr, ctx, keys, owned)
-            else:
-                slab = eng.cx_accumulate(None, ctx, keys, owned)
-            dist.all_reduce(slab, op=dist.ReduceOp.SUM)
-            return eng.cx_finish(ctx)
-
-        cols = step()
+        step = lambda: D.sharded_cytosine_report(eng, threshold_reads=wl["threshold"], report_context=wl["report_context"], gather=False)
+        rep = step()
         ref = res["rep"]
-        same = bool(all(torch.equal(cols[i], ref[k]) for i, k in enumerate(("rname", "strand", "pos", "context", "meth", "unmeth"))))
+        same = bool(all(torch.equal(rep[k], ref[k]) for k in ref))
+        xbytes = int(eng.last_exchange_bytes)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -402,17 +390,17 @@ def sharded_one_rank(cx, wl, res, steps):
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        slab_bytes = int(eng._slab.numel() * eng._slab.element_size())
     finally:
-        if made_group:
-            dist.destroy_process_group()
+        eng.close_comm()
     if not same:
         raise SystemExit("sharded_1rank: the table through the shared-tile path differs from the plain call's")
+    if xbytes <= 0:
+        raise SystemExit("sharded_1rank: the all-reduce carried no bytes")
     return {"ms_per_step": round(ms, 4), "plain_ms_per_step": round(res["ms_per_step"], 4),
-            "overhead_ms": round(ms - res["ms_per_step"], 4), "shared_tiles": 14, "all_reduce_bytes": slab_bytes,
-            "backend": "nccl (RCCL), world size 1", "table_equal_to_plain": True,
-            "what": "the same workload through the sharded driver on one rank: 14 forced shared tiles dumped to the slab, "
-                    "all_reduce(sum) of the slab, owners' emit, ordered columns"}
+            "overhead_ms": round(ms - res["ms_per_step"], 4), "shared_tiles": 14, "all_reduce_bytes": xbytes,
+            "backend": "RCCL called by the library (epi_comm, world size 1)", "table_equal_to_plain": True,
+            "what": "the same workload through epi_batch_cytosine_report_sharded on one rank: 14 forced shared tiles dumped to the "
+                    "slab, ncclAllReduce(sum) of the slab on the report's stream, owners' emit, ordered columns"}
 
 
 def host_out(cx, wl, res, steps=5):
@@ -626,7 +614,8 @@ def main():
                        "stream": wl.get("stream", "uniform"), "n_chr": n_chr_for(world),
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
                        "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
-                                    % ("RCCL" if args.backend == "nccl" else args.backend + ", a rehearsal without RCCL",
+                                    % ("RCCL, called by the library: epi_batch_*_report_sharded" if args.backend == "nccl" and not args.share_gpu
+                                       else args.backend + " through torch.distributed, a rehearsal without RCCL",
                                        "gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
@@ -648,6 +637,8 @@ def main():
     elif out is not None:
         out["cpu_baseline"] = None                   # --cpu-sample 0 / N > 1: not timed in this run
     del rep
+    if res.get("eng") is not None:
+        res["eng"].close_comm()
     res.pop("rep", None); res.pop("eng", None)
     bam.close()
     del bam

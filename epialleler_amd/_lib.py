@@ -129,6 +129,15 @@ _SIGS = {
     "epi_mhl_fused_tile_positions": (C.c_int, []),
     "epi_batch_mhl_fused_ok": (C.c_int, [_VP, _CS, _VP, C.POINTER(_I32)]),
     "epi_batch_mhl_set_shared_fused": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
+    "epi_comm_unique_id": (C.c_int, [_VP]),
+    "epi_comm_create": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "epi_comm_free": (None, [_VP]),
+    "epi_comm_rank": (C.c_int, [_VP]),
+    "epi_comm_world": (C.c_int, [_VP]),
+    "epi_comm_last_exchange_bytes": (_I64, [_VP]),
+    "epi_comm_set_test_shared": (None, [_VP, C.c_int]),
+    "epi_batch_cytosine_report_sharded": (C.c_int, [_VP, _VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _CS, _VP, _VP, C.POINTER(_I64)]),
+    "epi_batch_mhl_report_sharded": (C.c_int, [_VP, _VP, _CS, C.c_int, C.c_int, _F64, _VP, C.POINTER(_I64)]),
     "epi_synth_generate_dev": (C.c_int, [C.POINTER(SynthParams), _VP, _VP, _VP, _VP, _VP, _VP]),
     "epi_synth_fill_dev": (C.c_int, [C.c_uint64, _I64, _I64, _VP, _VP, _VP, _I64, _I32, _I32, _VP, _VP, _VP]),
     "epi_prof_enable": (None, [C.c_int]),

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 #include "../../include/epihip.h"
 
@@ -105,6 +106,8 @@ struct RowStats {          // filled by k_row_stats
 };
 }  // namespace epi
 
+struct epi_shard_plan;      // comm.hip: shared tile keys of a (batch, tile grid, communicator) triple
+
 struct epi_batch {
   epi_engine *eng = nullptr;
   int64_t n = 0, nbytes = 0;
@@ -167,6 +170,8 @@ struct epi_batch {
   std::vector<int32_t> dev_shared_owned;
   epi::DevBuf d_shared_keys, d_shared_owned, d_slot_tile;
   int32_t *d_slab = nullptr;
+  epi::DevBuf own_slab, own_slab2;       // the slabs of the library's own sharded entry points (comm.hip)
+  std::vector<std::shared_ptr<epi_shard_plan>> shard_plans;
   int32_t *d_mhl_cnt_slab = nullptr;     // lMHL shared tiles: counters and 64-bit sums
   int64_t *d_mhl_sum_slab = nullptr;
   uint32_t mhl_ctx_mask = 0;

@@ -21,9 +21,13 @@ ranks.  One exchange step:
      rows in HBM; the logical table is their concatenation in rank order (a report
      file is then written as one part per rank).
 
-The engine behind a shard is abstract (`ShardEngine`) so that the exchange logic
-runs unchanged on CPU tensors under gloo in tests (tests/fake_engine.py supplies
-a numpy engine there; the product engine is HipShardEngine, HIP only).
+Steps 1-5 exist twice.  The product path is INSIDE the library (csrc/comm.hip): an engine with a communicator
+attached (HipShardEngine.attach_comm: epi_comm_create = ncclCommInitRank, the id broadcast over torch.distributed) makes
+one C call per report -- epi_batch_cytosine_report_sharded / epi_batch_mhl_report_sharded -- in which RCCL is called
+directly on the report's stream; this module then only adds step 6.  The Python rendering of the same steps below
+(torch.distributed collectives around the two-step C entry points) serves engines without a communicator: the gloo
+rehearsals in which several ranks share one GPU (RCCL refuses that), and the CPU tests, where the engine is abstract
+(tests/fake_engine.py supplies a numpy engine; the product engine is HipShardEngine, HIP only).
 """
 import ctypes as C
 
@@ -77,6 +81,69 @@ class HipShardEngine:
         self._slab = None
         self._range = {}
         self.last_exchange_bytes = 0          # bytes this rank handed to the last report's all-reduce(s)
+        self.comm = None                      # epi_comm: RCCL behind the C ABI (attach_comm)
+
+    def attach_comm(self, group=None, test_shared=0):
+        """One RCCL communicator for this engine, created by the library (epi_comm_create = ncclCommInitRank; collective
+        over `group`).  Rank 0's id (epi_comm_unique_id) travels as a 128-byte tensor over torch.distributed -- the only
+        thing torch does for the sharded reports from here on.  test_shared > 0 (world size 1 only): that many tiles in
+        the middle of the shard are treated as shared, so that slab, all-reduce and the owners' emit run on one GPU."""
+        import torch.distributed as dist
+        torch = self.torch
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        idbuf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(self.lib.epi_comm_unique_id(idbuf))
+        if world > 1:
+            backend = dist.get_backend(group)
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=self.device if backend == "nccl" else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        from .api import _engine
+        h = C.c_void_p()
+        _lib.check(self.lib.epi_comm_create(_engine(self.bam.device), idbuf, rank, world, C.byref(h)))
+        self.comm = h
+        if test_shared:
+            self.lib.epi_comm_set_test_shared(h, int(test_shared))
+        return self
+
+    def close_comm(self):
+        if self.comm is not None:
+            self.lib.epi_comm_free(self.comm)
+            self.comm = None
+
+    def native_cx(self, pass_, ctx, threshold=None):
+        """epi_batch_cytosine_report_sharded: steps 1-5 in one C call; returns this rank's [6, nrow] columns."""
+        torch = self.torch
+        nrow = C.c_int64(0)
+        thr = threshold or (None, None, None, None, 0, 0.0, 0.0)
+        enc = lambda v: _lib.enc(v) if v is not None else None
+        _lib.check(self.lib.epi_batch_cytosine_report_sharded(
+            self.h, self.comm, enc(thr[0]), enc(thr[1]), enc(thr[2]), enc(thr[3]), int(thr[4]), float(thr[5]), float(thr[6]),
+            C.c_void_p(pass_.data_ptr()) if (pass_ is not None and threshold is None and self.bam.n) else None,
+            _lib.enc(ctx), None, _stream(self.bam.device), C.byref(nrow)))
+        n = nrow.value
+        cols = torch.empty((6, n), dtype=torch.int32, device=self.device)
+        if n:
+            _lib.check(self.lib.epi_batch_cx_fetch_dev(self.h, _ptr_array([cols[i] for i in range(6)]), _stream(self.bam.device)))
+        self.last_exchange_bytes = int(self.lib.epi_comm_last_exchange_bytes(self.comm))
+        return cols
+
+    def native_mhl(self, ctx, hmax, hmin, max_oo):
+        """epi_batch_mhl_report_sharded; returns this rank's ([5, nrow] int32, [2, nrow] float64) columns."""
+        torch = self.torch
+        nrow = C.c_int64(0)
+        _lib.check(self.lib.epi_batch_mhl_report_sharded(self.h, self.comm, _lib.enc(ctx), int(hmax), int(hmin), float(max_oo),
+                                                         _stream(self.bam.device), C.byref(nrow)))
+        n = nrow.value
+        icols = torch.empty((5, n), dtype=torch.int32, device=self.device)
+        dcols = torch.empty((2, n), dtype=torch.float64, device=self.device)
+        if n:
+            _lib.check(self.lib.epi_batch_mhl_fetch_dev(self.h, _ptr_array([icols[i] for i in range(5)]),
+                                                        _ptr_array([dcols[i] for i in range(2)]), _stream(self.bam.device)))
+        self.last_exchange_bytes = int(self.lib.epi_comm_last_exchange_bytes(self.comm))
+        return icols, dcols
 
     def tile_positions(self, ctx="Z"):
         """Positions per CX tile for this report context string (one reported context: 2048, else 1024)."""
@@ -273,6 +340,17 @@ def sharded_mhl_report(engine, ctx, hmax, hmin, max_ooctx_meth_frac, group=None,
     """rcpp_mhl_report over row-range shards (same exchange as the CX table, on 512-position tiles; the
     64-bit sums travel as int64 and add with wrap-around, which is what unsigned addition does)."""
     import torch.distributed as dist
+    if getattr(engine, "comm", None) is not None:          # RCCL behind the C ABI: steps 1-5 in one call
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        icols, dcols = engine.native_mhl(ctx, hmax, hmin, max_ooctx_meth_frac)
+        names = ("rname", "strand", "pos", "context", "coverage", "length", "lmhl")
+        if gather and world > 1:
+            got = _gather_rows([icols, dcols], group, world, rank, engine.device)
+            if got is None:
+                return None
+            icols, dcols = got
+        return Report(dict(zip(names, [icols[i] for i in range(5)] + [dcols[i] for i in range(2)])), levels)
     (ranges, fused), world, rank = _exchange_ranges(engine, "mhl", group, ctx)
     keys, owner = shared_tile_keys(ranges)
     owned = (owner == rank).astype(np.int32)
@@ -310,6 +388,17 @@ def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None, 
     rcpp_threshold_reads arguments: thresholding is then done inside the tile kernel (pass_ is ignored)."""
     import torch
     import torch.distributed as dist
+    names = ("rname", "strand", "pos", "context", "meth", "unmeth")
+    if getattr(engine, "comm", None) is not None:          # RCCL behind the C ABI: steps 1-5 in one call
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        cols = engine.native_cx(pass_, ctx, threshold)
+        if gather and world > 1:
+            got = _gather_rows([cols], group, world, rank, engine.device)
+            if got is None:
+                return None
+            cols = got[0]
+        return Report({k: cols[i] for i, k in enumerate(names)}, levels)
     ranges, world, rank = _exchange_ranges(engine, "cx", group, ctx)
     dev = engine.device
     keys, owner = shared_tile_keys(ranges)

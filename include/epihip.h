@@ -301,6 +301,35 @@ int epi_batch_mhl_fused_ok(epi_batch *b, const char *ctx, void *stream, int32_t 
 int epi_batch_mhl_set_shared_fused(epi_batch *b, const int64_t *h_keys, const int32_t *h_owned, int32_t nshared,
                                    int32_t *d_cnt_slab, int64_t *d_sum_slab);
 
+/* ---- the same exchange with RCCL called by the library (csrc/comm.hip) -------------------------------------------
+ * For hosts without a collective library of their own (the R shim): one epi_comm per process
+ * and GPU, one call per report.  The 128-byte id comes from ONE rank (epi_comm_unique_id = ncclGetUniqueId) and travels
+ * to the others by whatever the host has; epi_comm_create is collective (ncclCommInitRank).  Every rank then calls the
+ * sharded entry point on its own batch -- a contiguous range of the globally (rname, start)-sorted rows, ranges in rank
+ * order: tile key ranges are all-gathered (once per batch and tile grid), shared tiles accumulate into a slab owned by
+ * the batch, ncclAllReduce runs on the report's stream, owners emit.  nrow_out = THIS rank's rows; the reference's table
+ * is the ranks' tables in rank order (epi_batch_cx_fetch_* / epi_batch_mhl_fetch_* as after a single-GPU report).
+ * Replaces, for the sharded path, R/generateCytosineReport.R:181-203 and R/generateMhlReport.R:185-196 run on the whole
+ * data set.  ctx_meth == NULL: no thresholding (d_pass: per-row flags in device memory or NULL = all TRUE). */
+#define EPI_COMM_ID_BYTES 128
+typedef struct epi_comm epi_comm;
+int epi_comm_unique_id(void *id_out /* EPI_COMM_ID_BYTES */);
+int epi_comm_create(epi_engine *eng, const void *id /* EPI_COMM_ID_BYTES; may be NULL when world == 1 */, int rank, int world,
+                    epi_comm **out);
+void epi_comm_free(epi_comm *c);
+int epi_comm_rank(const epi_comm *c);
+int epi_comm_world(const epi_comm *c);
+int64_t epi_comm_last_exchange_bytes(const epi_comm *c);   /* bytes this rank handed to the last report's all-reduce(s) */
+/* Test hook (world size 1): treat `ntiles` consecutive tiles in the middle of the batch as shared, so that slab, collective
+ * and the owners' emit run on a one-GPU box (bench.py sharded_1rank, tests). */
+void epi_comm_set_test_shared(epi_comm *c, int ntiles);
+int epi_batch_cytosine_report_sharded(epi_batch *b, epi_comm *c, const char *ctx_meth, const char *ctx_unmeth,
+                                      const char *ooctx_meth, const char *ooctx_unmeth, uint32_t min_n_ctx,
+                                      double min_ctx_meth_frac, double max_ooctx_meth_frac, const int32_t *d_pass,
+                                      const char *ctx, int32_t *d_pass_out /* may be NULL */, void *stream, int64_t *nrow_out);
+int epi_batch_mhl_report_sharded(epi_batch *b, epi_comm *c, const char *ctx, int hmax, int hmin, double max_ooctx_meth_frac,
+                                 void *stream, int64_t *nrow_out);
+
 /* ---- synthetic input (bench/tests; DESIGN.md "Synthetic workload") ------- */
 typedef struct {
   uint64_t seed;

@@ -160,6 +160,54 @@ def test_rccl_single_rank_slab_roundtrip(tmp_path):
     H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "rccl_mhlf.npz"))), want, float_cols=("length", "lmhl"))
 
 
+def _native_worker(rank, port, outdir):
+    """RCCL behind the C ABI on one rank (csrc/comm.hip): epi_comm_create with a real unique id, 5 forced shared tiles, the
+    slab through a real ncclAllReduce inside epi_batch_*_report_sharded; no torch.distributed at all."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    torch.cuda.set_device(0)
+    import epialleler_amd as ea
+    from epialleler_amd import distributed as D
+    for name in ("wgs", "amplicon", "mixed"):
+        t = _case(name)
+        shard = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"])
+        eng = D.HipShardEngine(shard).attach_comm(test_shared=5)
+        for thr, rctx in ((True, "CG"), (False, "CX")):
+            for _ in range(2):                              # (the second call reuses the remembered plan)
+                rep = D.sharded_cytosine_report(eng, threshold_reads=thr, report_context=rctx, gather=True)
+            assert eng.last_exchange_bytes > 0
+            np.savez(os.path.join(outdir, "native_%s_%s.npz" % (name, rctx)), **{k: v.cpu().numpy() for k, v in rep.items()})
+        for hmax in (0, 2):
+            rep = D.sharded_mhl(eng, max_haplotype_window=hmax, gather=True)
+            assert eng.last_exchange_bytes > 0
+            np.savez(os.path.join(outdir, "native_%s_mhl%d.npz" % (name, hmax)), **{k: v.cpu().numpy() for k, v in rep.items()})
+        # the plain calls on the same batch afterwards: the shared-tile state must be gone
+        plain = ea.generateCytosineReport(shard, threshold_reads=True)
+        np.savez(os.path.join(outdir, "native_%s_plain.npz" % name), **dict(plain))
+        eng.close_comm()
+        shard.close()
+
+
+def test_library_comm_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_native_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    c = H.CONTEXT_TO_BASES["CG"]
+    for name in ("wgs", "amplicon", "mixed"):
+        t = _case(name)
+        p = orc.threshold_reads(t["xm"], t["off"], c["ctx_meth"], c["ctx_unmeth"], c["ooctx_meth"], c["ooctx_unmeth"], 2, 0.5, 0.1)
+        for thr, rctx, letters in ((True, "CG", "Z"), (False, "CX", "ZXH")):
+            want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p if thr else None, letters)
+            H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "native_%s_%s.npz" % (name, rctx)))), want)
+        H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "native_%s_plain.npz" % name))),
+                               orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], p, "Z"))
+        for hmax in (0, 2):
+            want = orc.mhl_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], "Zz", hmax, 0, 0.1)
+            H.assert_reports_equal(dict(np.load(os.path.join(str(tmp_path), "native_%s_mhl%d.npz" % (name, hmax)))), want,
+                                   float_cols=("length", "lmhl"))
+
+
 def _nccl_worker(rank, world, port, outdir):
     """Real RCCL ranks, one GPU each (needs >= 2 devices): sharded CX and lMHL tables gathered on rank 0."""
     sys.path.insert(0, HERE)
@@ -180,10 +228,15 @@ def _nccl_worker(rank, world, port, outdir):
         off = t["off"][lo:hi + 1]
         shard = ea.ProcessedBam.from_arrays(t["xm"][int(off[0]):int(off[-1])], off - off[0], t["rname"][lo:hi],
                                             t["strand"][lo:hi], t["start"][lo:hi], device=rank)
-        eng = D.HipShardEngine(shard)
+        eng = D.HipShardEngine(shard).attach_comm()          # RCCL behind the C ABI: epi_batch_*_report_sharded
         rep = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True)
         m = D.sharded_mhl(eng, gather=True)
+        assert eng.last_exchange_bytes > 0
+        eng.close_comm()
+        eng2 = D.HipShardEngine(shard)                      # ... and the same exchange through torch.distributed
+        rep2 = D.sharded_cytosine_report(eng2, threshold_reads=True, report_context="CG", gather=True)
         if rank == 0:
+            assert all(torch.equal(rep[k], rep2[k]) for k in rep)
             np.savez(os.path.join(outdir, "nccl_%s_cx.npz" % name), **{k: v.cpu().numpy() for k, v in rep.items()})
             np.savez(os.path.join(outdir, "nccl_%s_mhl.npz" % name), **{k: v.cpu().numpy() for k, v in m.items()})
     dist.barrier()
