@@ -217,11 +217,18 @@ int epi_batch_cytosine_report_sharded(epi_batch *b, epi_comm *c, const char *ctx
   EPI_TRY(epi_batch_cx_set_shared(b, plan->keys.data(), plan->owned.data(), nshared, nshared ? b->own_slab.as<int32_t>() : nullptr));
   int rc;
   int64_t nrow = 0;
-  if (ctx_meth)
-    rc = epi_batch_cytosine_report_dev(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac, ctx,
-                                       d_pass_out, s, &nrow);
-  else
-    rc = epi_batch_cx_report_dev(b, d_pass, ctx, s, &nrow);
+  auto first_half = [&]() {
+    if (ctx_meth)
+      return epi_batch_cytosine_report_dev(b, ctx_meth, ctx_unmeth, ooctx_meth, ooctx_unmeth, min_n_ctx, min_ctx_meth_frac, max_ooctx_meth_frac,
+                                           ctx, d_pass_out, s, &nrow);
+    return epi_batch_cx_report_dev(b, d_pass, ctx, s, &nrow);
+  };
+  // ONE host synchronisation per report where the batch allows it (an earlier report found no ultra-deep tile the host
+  // would have to finish before the slab travels): the first half only queues its kernels, the all-reduce and the owners'
+  // emit are queued behind them, and everything is read back and checked once, in the second half.
+  b->cx_defer = true;
+  rc = first_half();
+  b->cx_defer = false;
   if (rc == EPI_OK && nshared > 0) {
     // 4: the one data-path collective, queued on the report's stream behind the tile kernels
     if (c->nccl) {
@@ -231,6 +238,16 @@ int epi_batch_cytosine_report_sharded(epi_batch *b, epi_comm *c, const char *ctx
     }
     // 5: owners emit their shared tiles; rows ordered
     if (rc == EPI_OK) rc = epi_batch_cx_finish_shared(b, ctx, s, &nrow);
+    if (rc == EPI_RETRY_POOL) {
+      // (deferred synchronisation only) the row pool was too small: the first half again, with its own synchronisation --
+      // it grows the pool -- into a scratch slab; the shared tiles are then emitted from the slab that is already reduced
+      rc = b->own_slab2.ensure(slab_bytes);
+      if (rc == EPI_OK && hipMemsetAsync(b->own_slab2.p, 0, slab_bytes, s) != hipSuccess) rc = fail(EPI_ERR_HIP, "hipMemsetAsync failed");
+      if (rc == EPI_OK) rc = epi_batch_cx_set_shared(b, plan->keys.data(), plan->owned.data(), nshared, b->own_slab2.as<int32_t>());
+      if (rc == EPI_OK) rc = first_half();
+      if (rc == EPI_OK) rc = epi_batch_cx_set_shared(b, plan->keys.data(), plan->owned.data(), nshared, b->own_slab.as<int32_t>());
+      if (rc == EPI_OK) rc = epi_batch_cx_finish_shared(b, ctx, s, &nrow);
+    }
   }
   (void)epi_batch_cx_set_shared(b, nullptr, nullptr, 0, nullptr);     // later single-GPU calls on this batch emit every tile
   if (rc != EPI_OK) return rc;

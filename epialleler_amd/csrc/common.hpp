@@ -23,6 +23,7 @@ int fail(int code, const char *fmt, ...);
   } while (0)
 
 #define EPI_TRY(expr) do { int _rc = (expr); if (_rc != EPI_OK) return _rc; } while (0)
+constexpr int EPI_RETRY_POOL = -77;   // internal (never leaves the library): a deferred sharded report found its row pool too small
 
 // ---- geometry ---------------------------------------------------------------
 #ifndef EPI_CX_TILE
@@ -141,6 +142,15 @@ struct epi_batch {
   epi::DevBuf mhlf_fold_slab;                  // call counters of tiles over 255 rows (kernels built without the LDS fold array)
   bool mhl_shared_fused = false;               // the lMHL slabs attached are in the fused kernel's layout (mhl_common.hpp)
   uint32_t cx_last_slot = 0, cx_last_ovf = 0;  // layout of the last CX report (the sharded second half emits into it)
+  // One host synchronisation for a sharded CX report (comm.hip): with cx_defer set the first half queues its kernels and
+  // returns without reading anything back; the second half reads and checks everything at once.  Allowed only when an
+  // earlier report on this (immutable) batch and tile size found no ultra-deep tile that the host would have to finish
+  // before the slab may travel (cx_noheavy_T / _rows: the tile size and threshold that was observed for).
+  bool cx_defer = false, cx_deferred = false;
+  bool cx_def_hinted = false;
+  uint32_t cx_def_heavy_done = 0;
+  size_t cx_def_headroom = 0;
+  int32_t cx_noheavy_T = 0, cx_noheavy_rows = 0;
   int cx_last_np = 0;                          // ... its number of reported contexts and their codes
   uint32_t cx_last_ctx_of_plane = 0;
   epi::DevBuf pass_tmp;                        // pass flags when thresholding could not be fused and the caller wants none

@@ -1579,6 +1579,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   EPI_HIP(hipMemsetAsync(a.dbg, 0, 32, s));
 #endif
   uint32_t used_total[2] = {0, 0};
+  bool host_heavy = false;                                 // ultra-deep tiles had to be finished after the synchronisation
+  b->cx_deferred = false;
   for (int attempt = 0; attempt < 2; attempt++) {
     a.pool_key = b->pool_key.as<uint32_t>();
     a.pool_meth = b->pool_a.as<uint32_t>();
@@ -1614,6 +1616,17 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       prof_end("cx_heavy", s);
     }
     EPI_HIP(hipGetLastError());
+    if (b->cx_defer && nshared > 0 && attempt == 0 && nt_hinted && b->cx_noheavy_T == T && b->cx_noheavy_rows == a.heavy_rows) {
+      // sharded report with one host synchronisation: nothing is read back here; epi_batch_cx_finish_shared checks the tile
+      // count, the heavy-tile count and the pool at its own synchronisation (comm.hip reruns the first half into a scratch
+      // slab if the pool turns out too small)
+      b->cx_deferred = true;
+      b->cx_def_hinted = nt_hinted;
+      b->cx_def_heavy_done = chained ? CX_HEAVY_CAP : 0u;
+      b->cx_def_headroom = headroom;
+      b->last_kind = 3;
+      return EPI_OK;
+    }
     // row offsets of the tiles are queued right away; {rows handed out, total rows, heavy tiles} come back in one sync
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
     uint32_t host9[9];
@@ -1625,6 +1638,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
     }
     const uint32_t heavy_done = chained ? CX_HEAVY_CAP : 0u;
     if (host[2] > heavy_done) {
+      host_heavy = true;
+      b->cx_noheavy_T = 0;
       // ultra-deep tiles were set aside (and not finished above): split each over ceil(rows/chunk) workgroups, reduce in
       // HBM, emit, rescan
       const uint32_t nheavy = host[2] - heavy_done, nchunks = (host[7] + (uint32_t)a.heavy_chunk - 1) / (uint32_t)a.heavy_chunk;
@@ -1656,6 +1671,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
       EPI_HIP(hipMemsetAsync(b->d_slab, 0, (size_t)nshared * kCxPlanes * T * 4, s));
   }
   if (used_total[0] > used_total[1] / 8 && slot_state < (uint32_t)(2 * T)) slot_state *= 2;   // too many tiles outgrew their slot
+  // (no ultra-deep tile was left for the host to finish: a later sharded report on this batch may defer its synchronisation)
+  if (!host_heavy) { b->cx_noheavy_T = T; b->cx_noheavy_rows = a.heavy_rows; }
   if (nshared > 0) { b->last_kind = 3; return EPI_OK; }     // caller continues with epi_batch_cx_finish_shared
   b->last_kind = 1;
   b->last_nrow = used_total[1];
@@ -1726,7 +1743,29 @@ int epi_batch_cx_finish_shared(epi_batch *b, const char *ctx, void *stream, int6
   uint32_t *d_total = b->misc.as<uint32_t>() + 2;
   EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, d_total, b->scan_tmp, s));
   uint32_t ut[2] = {0, 0};                                  // {overflow rows handed out, total rows}: one sync
-  EPI_TRY(read_scalars(b, s, cursor, 8, ut));
+  if (b->cx_deferred) {
+    // the first half read nothing back: its checks happen here, with the report's only synchronisation
+    b->cx_deferred = false;
+    uint32_t host9[9];
+    EPI_TRY(read_scalars(b, s, cursor - 1, 36, host9));     // misc[0..8]
+    if (b->cx_def_hinted && host9[0] != (uint32_t)nt) {
+      for (int i = 0; i < 4; i++) b->tile_hint_T[i] = 0;
+      return fail(EPI_ERR_STATE, "the rows of this batch changed since an earlier report (tile count %u, was %d)", host9[0], nt);
+    }
+    if (host9[3] > b->cx_def_heavy_done) {
+      b->cx_noheavy_T = 0;
+      return fail(EPI_ERR_STATE, "ultra-deep tiles appeared in a batch that had none (%u): the rows of this batch changed", host9[3]);
+    }
+    if ((size_t)a.ovf_base + host9[1] > a.pool_cap) {         // (the cursor has served the shared tiles' rows as well by now)
+      // the pool was too small for the rows of this report: the caller reruns the first half (which grows it) into a
+      // scratch slab and emits the shared tiles from the slab that has already been reduced
+      b->last_kind = 0;
+      return EPI_RETRY_POOL;
+    }
+    ut[0] = host9[1]; ut[1] = host9[2];
+  } else {
+    EPI_TRY(read_scalars(b, s, cursor, 8, ut));
+  }
   // cannot overflow: the first half kept 2*kTile rows per shared tile free
   if ((size_t)a.ovf_base + ut[0] > a.pool_cap) return fail(EPI_ERR_STATE, "row pool overflow in sharded report");
   const uint32_t total = ut[1];

@@ -190,6 +190,39 @@ def _native_worker(rank, port, outdir):
         shard.close()
 
 
+def _native_retry_worker(rank, port, outdir):
+    """The deferred synchronisation's fallback: with EPIHIP_CX_SLOT=0 every row goes through the overflow region of the pool,
+    which the first report (CG) sizes for itself; the CHH report behind it -- four times the rows, one synchronisation, checks
+    at the end -- finds the pool too small and reruns its first half into a scratch slab."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["EPIHIP_CX_SLOT"] = "0"
+    import torch
+    torch.cuda.set_device(0)
+    import epialleler_amd as ea
+    from epialleler_amd import distributed as D
+    t = synth_np.generate(n_total=60000, read_len=300, n_chr=2)
+    shard = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"])
+    eng = D.HipShardEngine(shard).attach_comm(test_shared=5)
+    for rctx in ("CG", "CG", "CHH", "CHH"):
+        rep = D.sharded_cytosine_report(eng, threshold_reads=False, report_context=rctx, gather=False)
+        np.savez(os.path.join(outdir, "retry_%s.npz" % rctx), **{k: v.cpu().numpy() for k, v in rep.items()})
+    eng.close_comm()
+    shard.close()
+
+
+def test_library_comm_pool_retry(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_native_retry_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    t = synth_np.generate(n_total=60000, read_len=300, n_chr=2)
+    for rctx, letters in (("CG", "Z"), ("CHH", "H")):
+        want = orc.cx_report(t["xm"], t["off"], t["rname"], t["strand"], t["start"], None, letters)
+        got = dict(np.load(os.path.join(str(tmp_path), "retry_%s.npz" % rctx)))
+        assert got["pos"].size > (65536 if rctx == "CHH" else 1000)
+        H.assert_reports_equal(got, want)
+
+
 def test_library_comm_single_rank(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_native_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
