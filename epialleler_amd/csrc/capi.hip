@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <map>
 #include <mutex>
 
 using namespace epi;
@@ -35,6 +36,69 @@ static int upload_xm_only(epi_engine *eng, const uint8_t *xm, const int64_t *off
   return epi_batch_upload(eng, xm, off, zeros.data(), zeros.data(), zeros.data(), n, &g.b);
 }
 
+// The columns of a library-owned table are ONE allocation (epi_*_table_free releases the first column's pointer):
+// 2 MiB-aligned and advised as huge pages when large, so that the first touch by the copy threads faults 2 MiB at a time
+// (six separate 28 MB mallocs cost ~25 ms of page faults and unmapping per 7 M-row table).  Large blocks that come back
+// through epi_*_table_free are recycled: a caller that asks for report after report (what an R session does) gets the
+// pages of the table it has just released.
+namespace epi {
+namespace {
+struct TableBlocks {
+  std::mutex mu;
+  std::map<void *, size_t> live;                 // large blocks handed out: their sizes
+  struct Kept { void *p; size_t bytes; } kept[2] = {{nullptr, 0}, {nullptr, 0}};
+  ~TableBlocks() { for (auto &k : kept) free(k.p); }
+};
+TableBlocks &table_blocks() { static TableBlocks t; return t; }
+constexpr size_t kHuge = (size_t)2 << 20, kKeepMin = (size_t)8 << 20, kKeepMax = (size_t)1 << 30;
+}  // namespace
+
+void *table_block(size_t bytes) {
+  if (bytes >= 4 * kHuge) {
+    const size_t r = (bytes + kHuge - 1) & ~(kHuge - 1);
+    TableBlocks &t = table_blocks();
+    {
+      std::lock_guard<std::mutex> lk(t.mu);
+      for (auto &k : t.kept)
+        if (k.p && k.bytes >= r && k.bytes <= r + r / 2) {     // (no more than half again as large as asked for)
+          void *p = k.p;
+          t.live[p] = k.bytes;
+          k.p = nullptr; k.bytes = 0;
+          return p;
+        }
+    }
+    void *p = aligned_alloc(kHuge, r);
+    if (p) {
+      (void)madvise(p, r, MADV_HUGEPAGE);
+      std::lock_guard<std::mutex> lk(t.mu);
+      t.live[p] = r;
+      return p;
+    }
+  }
+  return malloc(bytes ? bytes : 16);
+}
+
+void table_block_release(void *p) {
+  if (!p) return;
+  TableBlocks &t = table_blocks();
+  void *drop = p;
+  {
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.live.find(p);
+    if (it != t.live.end()) {
+      const size_t bytes = it->second;
+      t.live.erase(it);
+      if (bytes >= kKeepMin && bytes <= kKeepMax) {
+        // keep it in place of an empty slot, or of the smaller kept block
+        int slot = !t.kept[0].p ? 0 : !t.kept[1].p ? 1 : (t.kept[0].bytes <= t.kept[1].bytes ? 0 : 1);
+        if (!t.kept[slot].p || t.kept[slot].bytes <= bytes) { drop = t.kept[slot].p; t.kept[slot].p = p; t.kept[slot].bytes = bytes; }
+      }
+    }
+  }
+  free(drop);
+}
+}  // namespace epi
+
 extern "C" {
 
 // ---- resident batch, host results: what an R / C / C++ caller without device memory of its own uses --------------
@@ -64,19 +128,6 @@ int epi_batch_get_xm_beta(epi_batch *b, const char *ctx_meth, const char *ctx_un
   return copy_to_host(b->eng, beta_out, d, (size_t)b->n * 8, s);
 }
 
-// The columns of a library-owned table are ONE allocation (epi_*_table_free releases the first column's pointer):
-// 2 MiB-aligned and advised as huge pages when large, so that the first touch by the copy threads faults 2 MiB at a time
-// (six separate 28 MB mallocs cost ~25 ms of page faults and unmapping per 7 M-row table).
-static void *table_block(size_t bytes) {
-  constexpr size_t HUGE = (size_t)2 << 20;
-  if (bytes >= 4 * HUGE) {
-    const size_t r = (bytes + HUGE - 1) & ~(HUGE - 1);
-    void *p = aligned_alloc(HUGE, r);
-    if (p) { (void)madvise(p, r, MADV_HUGEPAGE); return p; }
-  }
-  return malloc(bytes ? bytes : 16);
-}
-
 static int cx_table_to_host(epi_batch *b, int64_t nrow, hipStream_t s, epi_cx_table *out) {
   const size_t m = (size_t)(nrow > 0 ? nrow : 1);
   int32_t *base = static_cast<int32_t *>(table_block(6 * m * 4));
@@ -84,7 +135,7 @@ static int cx_table_to_host(epi_batch *b, int64_t nrow, hipStream_t s, epi_cx_ta
   int32_t *cols[6];
   for (int i = 0; i < 6; i++) cols[i] = base + (size_t)i * m;
   const int rc = epi_batch_cx_fetch_host(b, cols, s);
-  if (rc) { free(base); return rc; }
+  if (rc) { table_block_release(base); return rc; }
   out->nrow = nrow;
   out->rname = cols[0]; out->strand = cols[1]; out->pos = cols[2];
   out->context = cols[3]; out->meth = cols[4]; out->unmeth = cols[5];
@@ -161,7 +212,7 @@ int epi_batch_mhl_report(epi_batch *b, const char *ctx, int hmax, int hmin, doub
   int32_t *ic[5];
   for (int i = 0; i < 5; i++) ic[i] = reinterpret_cast<int32_t *>(base + 2 * m) + (size_t)i * m;
   const int rc = epi_batch_mhl_fetch_host(b, ic, dc, s);
-  if (rc) { free(base); return rc; }
+  if (rc) { table_block_release(base); return rc; }
   out->nrow = nrow;
   out->rname = ic[0]; out->strand = ic[1]; out->pos = ic[2]; out->context = ic[3]; out->coverage = ic[4];
   out->length = dc[0]; out->lmhl = dc[1];

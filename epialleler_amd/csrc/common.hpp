@@ -198,6 +198,12 @@ int copy_parts_to_host(epi_engine *eng, const CopyPart *parts, int nparts, hipSt
 int copy_to_host(epi_engine *eng, void *h_dst, const void *d_src, size_t bytes, hipStream_t s);
 int read_scalars(epi_batch *b, hipStream_t s, const void *d_src, size_t bytes, void *h_dst);  // sync D2H of a few bytes
 
+// Host blocks of library-owned report tables (capi.hip).  A large block given back by epi_*_table_free is kept (two blocks,
+// at most 1 GiB) and handed to the next table of a similar size: its pages are already mapped, where a fresh 168 MB block
+// costs ~9 ms of page faults on the copy threads -- twice the copy itself.
+void *table_block(size_t bytes);
+void table_block_release(void *p);
+
 // util kernels (util.hip)
 int scan_exclusive_u32(const uint32_t *d_in, uint32_t *d_out, int64_t n, uint32_t *d_total,
                        DevBuf &tmp, hipStream_t s);

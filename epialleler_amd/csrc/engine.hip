@@ -432,13 +432,13 @@ int64_t epi_batch_nrows(const epi_batch *b) { return b ? b->n : -1; }
 
 void epi_cx_table_free(epi_cx_table *t) {                // (the columns are one allocation, capi.hip: rname is its start)
   if (!t) return;
-  free(t->rname);
+  epi::table_block_release(t->rname);
   memset(t, 0, sizeof(*t));
 }
 
 void epi_mhl_table_free(epi_mhl_table *t) {              // (one allocation: length is its start)
   if (!t) return;
-  free(t->length);
+  epi::table_block_release(t->length);
   memset(t, 0, sizeof(*t));
 }
 

@@ -12,23 +12,33 @@
 //     positions that hold a call), folded into wider counters every 255 rows,
 // and a row of the table exists iff n > cov/2 (then no other context can win the majority rule, :76-86).
 //
-// Round 3 rewrite (the kernel is bound by integer VALU issue):
-//   * The member / in-context bit planes come from SWAR compares on the raw dwords (xor with the context code, add 7:
-//     bit 3 of a byte says "not this context"; the case bit of the packed code is bit 3 as well) -- plain two-operand
-//     VALU -- and ONE v_dot4 per plane and pair of dwords gathers the flags of eight bytes into a mask byte.  The
-//     out-of-context counts, which need no positions, are 2-bit fields of a second byte LUT, summed field-wise and by
-//     v_sad_u8 (the per_read.hip scheme).  Round 2 built four planes through a v_perm LUT and eight v_dot4 per pair.
-//   * Bytes outside the row are zeroed once after the load (code 0 has no flag), instead of masking every plane.
-//   * Skipped ('+', '-', filler) and stray codes (nibbles 3, 4, 8, 9 alias the reference's sum / coverage slots) only
-//     raise a flag in the counting LUT; the lanes that see one reload their bytes (an L1 hit) and build those planes on
-//     the spot.  Nothing but the in-context pair flags stays live across the row's decision.
-//   * Emit: seven wavefronts prefix-sum the seven difference arrays in place (one array each, four quads per lane: no
-//     bank conflicts, 28 wavefront scans per tile where round 2 ran 56 plus cross-wave fix-ups), and only the cells
-//     that hold a call (3.5 % for CpG) read the sums.
+// How the row analysis is built (the kernel is bound by integer VALU issue; every item below replaced
+// something that cost more instructions per row):
+//   * Lane shape: G lanes own a row, a lane holds 16 (CA + CB) contiguous bytes as one mask block (CB = 0: up to 64 bytes,
+//     64-bit masks) or two (CA = 3, CB = 2: 80 bytes as a 48-byte and a 32-byte block, combined like two lanes before the
+//     lane scans): PE150 templates are 4 lanes x 80 bytes, 16 rows per wavefront step, 256-thread workgroups.
+//   * Row bytes come through a raw buffer descriptor over the tile's stretch of xm (32-bit offsets, unaligned b128 loads;
+//     a chunk the row does not reach is sent out of range and reads as zeros); bytes outside the row are zeroed once after
+//     the load (code 0 has no flag) instead of masking every plane.
+//   * The member / in-context bit planes come from SWAR compares on the nibble-packed codes of two dwords
+//     (((pk & 7..7) ^ k..k) + 7..7: bit 3 of a nibble says "not this context"; the case bit of a code is its bit 3) -- plain
+//     two-operand VALU -- and ONE v_dot4 per plane and pair of dwords gathers the flags of eight bytes into a mask byte.
+//   * The out-of-context counts need no positions: 2-bit fields of a 16-entry byte LUT (two v_perm_b32 and an XOR,
+//     lut16_xor_form in common.hpp), summed field-wise and by v_sad_u8 (the per_read.hip scheme).
+//   * Skipped ('+', '-', filler) and stray codes (nibbles 3, 4, 8, 9 alias the reference's sum / coverage slots) only raise
+//     a flag in the counting LUT; a lane that sees one builds that plane from the bytes it STILL HOLDS in registers
+//     (mhlf_eq_plane) -- nothing is reloaded.  The fast variant hands a tile with a stray code to the WIDE one.
+//   * Stretches: span bits by carry propagation (mhlf_fill_up), S(members) per run from a table in LDS (k < 256); where the
+//     lane holds no skipped byte a segment's span is one run and its member count a popcount.
+//   * Emit: the seven difference arrays are prefix-summed in place, one array per wavefront at a time (lane l owns the quads
+//     64 j + l: conflict-free ds_read_b128, 28 wavefront scans per tile); every thread rules on its own positions, the cells
+//     that become rows are listed in key order in the (by then dead) coverage array and written densely, one row per lane.
+//   * LDS 31.8 KB without the fold array (FOLD = false: five workgroups per CU; a tile of more than 255 rows folds its u8
+//     call counters into a slot of a slab in HBM), 35.8 KB with it (four per CU); 96 VGPRs, no scratch.
 //   * No whole-batch fallback: a tile whose u32 sums could wrap (checked after the rows, from the rows' own S(h)), with
-//     more than 32767 candidate rows, or forced by the test hook, is put on a list and redone by the WIDE variant
-//     (u64 sums, u32 coverage and call counters: no limit) -- only that tile.  Tiles shared with other ranks of a
-//     sharded run dump their raw arrays into the slabs the ranks all-reduce (distributed.py) instead of emitting.
+//     more than 32767 candidate rows, or with a stray code is put on a list and redone by the WIDE variant (u64 sums, u32
+//     coverage and call counters: no limit) -- only that tile.  Tiles shared with other ranks of a sharded run dump their raw
+//     arrays into the slabs the ranks all-reduce (comm.hip / distributed.py) instead of emitting.
 #include "common.hpp"
 #include "mhl_common.hpp"
 #include <string.h>
