@@ -17,7 +17,11 @@ Besides the contract line's `value` (inputs resident in HBM) the N=1 line carrie
   streamed   the same report with the batch starting in pinned host memory (upload + report), SURVEY 8d
   d2h        the report table copied to pinned host memory
   host_out   the report as a host binding (the R shim) gets it: table in host memory, one-call and two-step forms
-  sharded_1rank  the same step through the sharded driver on one rank: 14 forced shared tiles + a real RCCL all-reduce
+  selfcheck  N=1: the last timed report of the timed batch against the CPU oracle on three row windows (exit non-zero on a difference)
+  tile_hint_off  the step with EPIHIP_TILE_HINT=0 (tile index counted and scanned by every call)
+  n1_same_stream  the step at N=1 on the 3-chromosome stream the N>1 runs use (the base for a 1 -> N ratio)
+  sharded_1rank  the same step through epi_batch_cytosine_report_sharded (RCCL inside the library) on one rank: 14 forced shared
+             tiles + a real ncclAllReduce
   cfg2g / cfg2u / cfg2p   the stream's effects apart: round 1/2's jittered-grid starts / ragged lengths and gapped
              mates / one 20 000-row pile-up in the stream
   strong_cfg3  BASELINE config 3 (100 M templates in total, split over the N GPUs)
