@@ -596,6 +596,10 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
   __shared__ uint32_t s_scan[NW + 2];
   __shared__ uint32_t s_tab[MHLF_STAB];                                              // S(k), k < MHLF_STAB (:110-116)
   __shared__ uint32_t s_hmax;                                                        // largest h among the kept rows; 0xFFFFFFFF: a stray code
+#ifdef EPI_MHLF_LDS_PAD                                    // timing builds: LDS nobody uses (how many workgroups fit a CU)
+  __shared__ uint32_t s_pad[EPI_MHLF_LDS_PAD / 4];
+  if (a.xm_cap == -12345) s_pad[threadIdx.x % (EPI_MHLF_LDS_PAD / 4)] = 1;
+#endif
   int tile;
   if (a.tile_list) {
     if ((int)blockIdx.x >= ntiles) return;
