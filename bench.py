@@ -295,6 +295,8 @@ def n1_selfcheck(cx, wl, res, L):
     SystemExit on a mismatch."""
     from oracle import windows as W
     rows = res["rows"]
+    if wl.get("stream") == "ragged":
+        L = L * 6 // 5                                     # template lengths 0.8-1.2 L: the trimmed margin is the LONGEST read
     wrows = 20000 if L <= 1000 else max(300, 20000 * 300 // L)
     letters = {"CG": "Z", "CHG": "X", "CHH": "H", "CxG": "ZX", "CX": "ZXH"}[wl.get("report_context", "CG")]
     fn = W.oracle_for(wl["kind"], wl.get("threshold", False), letters)
