@@ -129,6 +129,7 @@ _SIGS = {
     "epi_mhl_fused_tile_positions": (C.c_int, []),
     "epi_batch_mhl_fused_ok": (C.c_int, [_VP, _CS, _VP, C.POINTER(_I32)]),
     "epi_batch_mhl_set_shared_fused": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
+    "epi_shared_tile_keys": (C.c_int, [_VP, _I32, _VP, _VP, _I32, C.POINTER(_I32)]),
     "epi_comm_unique_id": (C.c_int, [_VP]),
     "epi_comm_create": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
     "epi_comm_free": (None, [_VP]),

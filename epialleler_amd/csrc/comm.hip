@@ -107,7 +107,7 @@ std::atomic<uint64_t> g_comm_serial{1};
 // all ranks' values (nvals int64 per rank) -> host
 int all_gather_i64(epi_comm *c, const int64_t *mine, int nvals, hipStream_t s, std::vector<int64_t> *all) {
   all->assign((size_t)nvals * c->world, 0);
-  if (c->world == 1) { std::copy(mine, mine + nvals, all->begin()); return EPI_OK; }
+  if (!c->nccl) { std::copy(mine, mine + nvals, all->begin()); return EPI_OK; }   // (world size 1 without a communicator)
   EPI_TRY(c->d_gather.ensure((size_t)nvals * 8 * (c->world + 1)));
   int64_t *d_send = c->d_gather.as<int64_t>(), *d_recv = d_send + nvals;
   EPI_HIP(hipMemcpyAsync(d_send, mine, (size_t)nvals * 8, hipMemcpyHostToDevice, s));
@@ -137,6 +137,19 @@ struct epi_shard_plan {                         // what a (batch, tile grid, com
 };
 
 extern "C" {
+
+// The shared tiles of a set of key ranges (pure host logic; what every rank derives from the all-gathered ranges).
+int epi_shared_tile_keys(const int64_t *ranges, int32_t world, int64_t *keys_out, int32_t *owner_out, int32_t cap, int32_t *n_out) {
+  if (!ranges || world < 1 || !n_out || (cap > 0 && (!keys_out || !owner_out))) return fail(EPI_ERR_ARG, "epi_shared_tile_keys: bad arguments");
+  std::vector<int64_t> all(ranges, ranges + 2 * (size_t)world), keys;
+  std::vector<int32_t> owner;
+  EPI_TRY(shared_keys_of(all, world, &keys, &owner));
+  *n_out = (int32_t)keys.size();
+  if ((int64_t)keys.size() > cap) return cap > 0 ? fail(EPI_ERR_ARG, "epi_shared_tile_keys: %zu keys do not fit %d", keys.size(), cap) : EPI_OK;
+  std::copy(keys.begin(), keys.end(), keys_out);
+  std::copy(owner.begin(), owner.end(), owner_out);
+  return EPI_OK;
+}
 
 int epi_comm_unique_id(void *id_out) {
   if (!id_out) return fail(EPI_ERR_ARG, "epi_comm_unique_id: NULL argument");

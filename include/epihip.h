@@ -311,6 +311,10 @@ int epi_batch_mhl_set_shared_fused(epi_batch *b, const int64_t *h_keys, const in
  * is the ranks' tables in rank order (epi_batch_cx_fetch_* / epi_batch_mhl_fetch_* as after a single-GPU report).
  * Replaces, for the sharded path, R/generateCytosineReport.R:181-203 and R/generateMhlReport.R:185-196 run on the whole
  * data set.  ctx_meth == NULL: no thresholding (d_pass: per-row flags in device memory or NULL = all TRUE). */
+/* Step 2 on its own (pure host logic, no device needed): ranges = (first, last) tile key per rank, first > last for a rank
+ * without rows; keys_out / owner_out (capacity cap; cap = 0: only count) receive the keys reachable from at least two ranks,
+ * ascending, and the lowest rank that reaches each.  What epialleler_amd/distributed.py's shared_tile_keys computes. */
+int epi_shared_tile_keys(const int64_t *ranges, int32_t world, int64_t *keys_out, int32_t *owner_out, int32_t cap, int32_t *n_out);
 #define EPI_COMM_ID_BYTES 128
 typedef struct epi_comm epi_comm;
 int epi_comm_unique_id(void *id_out /* EPI_COMM_ID_BYTES */);

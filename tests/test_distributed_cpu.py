@@ -87,3 +87,41 @@ def test_shared_tile_keys_logic():
     assert keys.size == 0
     with pytest.raises(ValueError):
         shared_tile_keys([(K(1, 5), K(2, 6)), (K(1, 7), K(2, 9))])
+
+
+def test_library_shared_tile_keys_match_the_python_rendering():
+    """csrc/comm.hip derives the shared tiles of a sharded report itself (epi_shared_tile_keys is that step on its own): the
+    same keys and owners as distributed.shared_tile_keys on random rank layouts -- contiguous shards with halos, ranks
+    without rows, amplicon-like total overlap, cuts at reference-sequence boundaries."""
+    import ctypes as C
+    import numpy as np
+    from epialleler_amd import _lib
+    from epialleler_amd.distributed import shared_tile_keys
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    cases = []
+    for _ in range(300):
+        world = int(rng.integers(1, 9))
+        ranges, pos, rname = [], int(rng.integers(0, 50)), int(rng.integers(1, 4))
+        for r in range(world):
+            if rng.random() < 0.15:
+                ranges.append((0, -1))                                  # a rank without rows
+                continue
+            if rng.random() < 0.2:
+                rname += 1; pos = int(rng.integers(0, 50))              # the shard starts on the next reference sequence
+            first = (rname << 32) | max(pos - int(rng.integers(0, 3)), 0)   # halo: reaches back into the previous rank's tiles
+            last = (rname << 32) | (pos + int(rng.integers(0, 40)))
+            ranges.append((first, last))
+            pos = (last & 0xFFFFFFFF) + int(rng.integers(0, 2))
+        cases.append(ranges)
+    cases.append([((1 << 32) | 5, (1 << 32) | 9)] * 4)                  # every rank reaches every tile
+    for ranges in cases:
+        want_k, want_o = shared_tile_keys(ranges)
+        flat = np.asarray(ranges, np.int64).reshape(-1)
+        n = C.c_int32(0)
+        _lib.check(lib.epi_shared_tile_keys(C.c_void_p(flat.ctypes.data), len(ranges), None, None, 0, C.byref(n)))
+        assert n.value == want_k.size
+        keys, owner = np.zeros(max(n.value, 1), np.int64), np.zeros(max(n.value, 1), np.int32)
+        _lib.check(lib.epi_shared_tile_keys(C.c_void_p(flat.ctypes.data), len(ranges), C.c_void_p(keys.ctypes.data),
+                                            C.c_void_p(owner.ctypes.data), int(keys.size), C.byref(n)))
+        assert np.array_equal(keys[:n.value], want_k) and np.array_equal(owner[:n.value], want_o)
