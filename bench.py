@@ -164,6 +164,27 @@ class Ctx:
         return int(t.item())
 
 
+def attach_native(cx, eng):
+    """N > 1 on RCCL: the shard's communicator is created by the library (epi_comm_create = ncclCommInitRank; csrc/comm.hip), so
+    that the report's exchange is one C call per rank.  Every rank must end up on the same path: whether the creation worked is
+    agreed on over torch.distributed, and if it failed anywhere every rank uses the torch.distributed rendering of the same
+    steps instead (the line's `sharding` field says which one ran)."""
+    if eng is None or cx.args.backend != "nccl" or cx.args.share_gpu:
+        return False
+    ok = 1
+    try:
+        eng.attach_comm()
+    except Exception as e:                                   # pragma: no cover (needs a broken RCCL set-up)
+        ok = 0
+        print("rank %d: epi_comm_create failed (%s); falling back to torch.distributed collectives" % (cx.rank, e), file=sys.stderr, flush=True)
+    t = cx.torch.tensor([ok], dtype=cx.torch.int64, device=cx.dev)
+    cx.dist.all_reduce(t, op=cx.dist.ReduceOp.MIN)
+    if int(t.item()) != 1:
+        eng.close_comm()
+        return False
+    return True
+
+
 def n_chr_for(world):
     """Chromosomes of the synthetic genome.  SURVEY 8d: 4.  With 2 or 4 ranks (and 4 of the 7 cuts at 8) equal row ranges
     of a 4-chromosome stream are cut exactly at chromosome boundaries: no tile is shared and the exchange step never
@@ -204,8 +225,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
     bam = make_batch(cx, wl, rows, L, n_total, n_chr=n_chr)
     cx.torch.cuda.synchronize()
     eng = cx.D.HipShardEngine(bam) if cx.world > 1 else None
-    if eng is not None and cx.args.backend == "nccl" and not cx.args.share_gpu:
-        eng.attach_comm()                                  # RCCL behind the C ABI (one communicator per rank, created by the library)
+    native = attach_native(cx, eng)                        # RCCL behind the C ABI (one communicator per rank, created by the library)
     step = make_step(cx, wl, bam, eng, gather)
     # setup, not steps: the first calls size the engine's row pool / record space for this workload and the caching
     # allocator's blocks for the two output tables that are alive at a time (rep = step() frees the previous one late)
@@ -230,7 +250,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
         if c2.value:
             kernels[nm.decode()] = round(m2.value / c2.value, 4)
     nrow_local = rep.nrow if rep is not None else 0
-    out = dict(dt=dt, ms_per_step=dt / steps * 1e3, n_total=n_total, rows=rows, L=L, kernels=kernels,
+    out = dict(dt=dt, ms_per_step=dt / steps * 1e3, n_total=n_total, rows=rows, L=L, kernels=kernels, native_comm=bool(native),
                nrow_local=nrow_local, nbytes_local=bam.nbytes,
                exchange_bytes=getattr(eng, "last_exchange_bytes", 0) if eng is not None else 0)
     if keep:
@@ -254,8 +274,7 @@ def selfcheck(cx, n_total):
     wl = WORKLOADS["cfg2"]
     bam = make_batch(cx, wl, rows, 300, n_total, seed=5)
     eng = D.HipShardEngine(bam)
-    if cx.args.backend == "nccl" and not cx.args.share_gpu:
-        eng.attach_comm()
+    attach_native(cx, eng)
     got_cx = D.sharded_cytosine_report(eng, threshold_reads=True, report_context="CG", gather=True, levels=bam.levels)
     xb_cx = cx.sum_over_ranks(eng.last_exchange_bytes)
     got_mhl = D.sharded_mhl(eng, gather=True, levels=bam.levels)
@@ -620,8 +639,9 @@ def main():
                        "stream": wl.get("stream", "uniform"), "n_chr": n_chr_for(world),
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
                        "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
-                                    % ("RCCL, called by the library: epi_batch_*_report_sharded" if args.backend == "nccl" and not args.share_gpu
-                                       else args.backend + " through torch.distributed, a rehearsal without RCCL",
+                                    % ("RCCL, called by the library: epi_batch_*_report_sharded" if res.get("native_comm")
+                                       else args.backend + " collectives of torch.distributed around the two-step C entry points"
+                                       + (", a rehearsal without RCCL" if args.backend != "nccl" else ""),
                                        "gathered to rank 0" if gathered else "stay sharded in rank order")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
