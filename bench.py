@@ -19,6 +19,7 @@ Besides the contract line's `value` (inputs resident in HBM) the N=1 line carrie
   host_out   the report as a host binding (the R shim) gets it: table in host memory, one-call and two-step forms
   selfcheck  N=1: the last timed report of the timed batch against the CPU oracle on three row windows (exit non-zero on a difference)
   tile_hint_off  the step with EPIHIP_TILE_HINT=0 (tile index counted and scanned by every call)
+  layout_off     the step on the same rows adopted back to back (no position-congruent copy; config.batch_ms is what the copy costs once)
   n1_same_stream  the step at N=1 on the 3-chromosome stream the N>1 runs use (the base for a 1 -> N ratio)
   sharded_1rank  the same step through epi_batch_cytosine_report_sharded (RCCL inside the library) on one rank: 14 forced shared
              tiles + a real ncclAllReduce
@@ -224,6 +225,10 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
     n_total = rows * cx.world
     bam = make_batch(cx, wl, rows, L, n_total, n_chr=n_chr)
     cx.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bam.batch()                                            # adopt + row statistics + the engine's own row layout (epi_batch_realign): once per batch
+    cx.torch.cuda.synchronize()
+    batch_ms = (time.perf_counter() - t0) * 1e3
     eng = cx.D.HipShardEngine(bam) if cx.world > 1 else None
     native = attach_native(cx, eng)                        # RCCL behind the C ABI (one communicator per rank, created by the library)
     step = make_step(cx, wl, bam, eng, gather)
@@ -251,6 +256,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
             kernels[nm.decode()] = round(m2.value / c2.value, 4)
     nrow_local = rep.nrow if rep is not None else 0
     out = dict(dt=dt, ms_per_step=dt / steps * 1e3, n_total=n_total, rows=rows, L=L, kernels=kernels, native_comm=bool(native),
+               batch_ms=batch_ms, layout=int(cx.lib.epi_batch_layout(bam.batch())),
                nrow_local=nrow_local, nbytes_local=bam.nbytes,
                exchange_bytes=getattr(eng, "last_exchange_bytes", 0) if eng is not None else 0)
     if keep:
@@ -353,6 +359,34 @@ def tile_hint_off(cx, wl, res, steps):
         cx.lib.epi_options_reload()
     return {"ms_per_step": round(ms, 4), "vs_hinted": round(ms / res["ms_per_step"], 3),
             "what": "EPIHIP_TILE_HINT=0: count pass + scan + host round trip for the tile count in every step"}
+
+
+def layout_off(cx, wl, res, steps):
+    """N=1 extra: the same step on the same rows adopted WITHOUT the engine's position-congruent copy (rows back to back as the
+    generator wrote them: the position-aligned chunks of the tile kernels then have any byte alignment)."""
+    bam = res["bam"]
+    d = bam.dev
+    raw = cx.ea.ProcessedBam.from_device(d["xm"], bam.nbytes, d["off"], d["rname"], d["strand"], d["start"], bam.levels, realign=False)
+    try:
+        import ctypes as C
+        step = make_step(cx, wl, raw, None, False)
+        for _ in range(3):
+            step()
+        cx.torch.cuda.synchronize()
+        cx.lib.epi_prof_reset()
+        cx.lib.epi_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        cx.torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        cx.lib.epi_prof_enable(0)
+        m2, c2 = C.c_double(0), C.c_int64(0)
+        cx.lib.epi_prof_get(b"mhl_tiles" if wl["kind"] == "mhl" else b"cx_tiles", C.byref(m2), C.byref(c2))
+    finally:
+        raw.close()
+    return {"ms_per_step": round(ms, 4), "vs_congruent": round(ms / res["ms_per_step"], 3), "kernel_ms": round(m2.value / max(c2.value, 1), 4),
+            "what": "rows back to back (epi_batch_adopt without epi_batch_realign): chunk loads at any byte alignment"}
 
 
 def streamed_and_d2h(cx, wl, res):
@@ -638,7 +672,11 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "rows_per_gpu": rows, "template_bytes": L,
                        "stream": wl.get("stream", "uniform"), "n_chr": n_chr_for(world),
                        "read_unit": "template row (merged pair); mates/s = 2x", "output_rows": int(nrow_out),
-                       "inputs": "resident in HBM", "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
+                       "inputs": "resident in HBM",
+                       "layout": ("rows at offsets congruent to their start position modulo %d in the engine's own copy of xm, made once per "
+                                  "batch by epi_batch_realign (batch_ms below; layout_off: the step without it)" % res["layout"]) if res.get("layout")
+                                 else "rows back to back as adopted",
+                       "batch_ms": round(res["batch_ms"], 3), "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
                                     % ("RCCL, called by the library: epi_batch_*_report_sharded" if res.get("native_comm")
                                        else args.backend + " collectives of torch.distributed around the two-step C entry points"
                                        + (", a rehearsal without RCCL" if args.backend != "nccl" else ""),
@@ -654,6 +692,8 @@ def main():
     extras = not args.no_extras and not args.rows and not args.read_len
     if world == 1 and extras and out is not None:
         out["tile_hint_off"] = tile_hint_off(cx, wl, res, max(3, args.steps // 2))
+        if res.get("layout"):
+            out["layout_off"] = layout_off(cx, wl, res, max(3, args.steps // 2))
     if world == 1 and extras and wl["kind"] == "cx" and L <= 1000 and out is not None:
         out["streamed"], out["d2h"] = streamed_and_d2h(cx, wl, res)
         out["host_out"] = host_out(cx, wl, res)

@@ -103,6 +103,9 @@ _SIGS = {
     "epi_batch_mhl_report_begin": (C.c_int, [_VP, _CS, C.c_int, C.c_int, _F64, C.POINTER(_I64)]),
     "epi_default_engine": (C.c_int, [C.POINTER(_VP)]),
     "epi_batch_nrows": (_I64, [_VP]),
+    "epi_batch_realign": (C.c_int, [_VP, _VP]),
+    "epi_batch_layout": (C.c_int, [_VP]),
+    "epi_batch_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_I64)]),
     "epi_batch_threshold_reads_dev": (C.c_int, [_VP, _CS, _CS, _CS, _CS, _U32, _F64, _F64, _VP, _VP]),
     "epi_batch_get_xm_beta_dev": (C.c_int, [_VP, _CS, _CS, _VP, _VP]),
     "epi_batch_match_target_dev": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),

@@ -79,6 +79,7 @@ class ProcessedBam:
         self.dev = None         # dict of torch tensors (kept alive for an adopted batch) or None
         self.device = None
         self._batch = None
+        self.realign = True     # adopted device columns: let the engine lay the rows out its own way (from_device)
         self._keep = None       # owner of the host buffers the numpy columns are views of (producer output, pinned tensors)
 
     @classmethod
@@ -108,13 +109,21 @@ class ProcessedBam:
                                keepalive=(xm, off, rname, strand, start), device=device)
 
     @classmethod
-    def from_device(cls, xm, nbytes, off, rname, strand, start, levels=None):
-        """Adopt torch tensors already in HBM (xm: uint8 with capacity >= nbytes rounded up to 16)."""
+    def from_device(cls, xm, nbytes, off, rname, strand, start, levels=None, realign=True):
+        """Adopt torch tensors already in HBM (xm: uint8 with capacity >= nbytes rounded up to 16).  realign: the engine
+        makes its own position-congruent copy of xm when the batch is created (epi_batch_realign, include/epihip.h) and
+        reads neither xm nor off afterwards; drop_source() then gives their memory back.  False: strictly zero-copy."""
         n = int(off.numel()) - 1
         self = cls(n, nbytes, levels)
         self.dev = dict(xm=xm, off=off, rname=rname, strand=strand, start=start)
         self.device = xm.device.index
+        self.realign = bool(realign)
         return self
+
+    def drop_source(self):
+        """After the batch exists in the engine's own layout: release the adopted xm / off tensors."""
+        if self.dev is not None and self._batch is not None and _lib.load().epi_batch_layout(self._batch) > 0:
+            self.dev = {k: v for k, v in self.dev.items() if k not in ("xm", "off")}
 
     def batch(self, device=None):
         """The epi_batch handle (uploads on first use through the library's pinned double-buffered path)."""
@@ -129,6 +138,11 @@ class ProcessedBam:
                                            C.c_void_p(d["off"].data_ptr()), C.c_void_p(d["rname"].data_ptr()),
                                            C.c_void_p(d["strand"].data_ptr()), C.c_void_p(d["start"].data_ptr()),
                                            self.n, C.byref(h)))
+            if getattr(self, "realign", True):
+                rc = lib.epi_batch_realign(h, None)
+                if rc:
+                    lib.epi_batch_free(h)
+                    _lib.check(rc)
         else:
             eng = _engine(device if device is not None else self.device)
             self.device = lib.epi_engine_device(eng)

@@ -94,6 +94,12 @@ struct epi_engine {
   void *pinned[2] = {nullptr, nullptr};
   size_t pinned_bytes = 0;
   hipEvent_t pinned_done[2] = {nullptr, nullptr};
+  // epi_batch_upload lays the rows out while they arrive (engine.hip, layout.hip): two device-side pieces of the source
+  // arena, filled by the copy stream and emptied into the batch's own arena by kernels on aux_stream
+  hipStream_t aux_stream = nullptr;
+  void *dev_stage[2] = {nullptr, nullptr};
+  size_t dev_stage_bytes = 0;
+  hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
   int32_t *h_scalars = nullptr;       // pinned scratch for small D2H reads (64 x int64)
 };
 
@@ -112,11 +118,18 @@ struct epi_shard_plan;      // comm.hip: shared tile keys of a (batch, tile grid
 struct epi_batch {
   epi_engine *eng = nullptr;
   int64_t n = 0, nbytes = 0;
+  // Rows as every kernel sees them: row x owns xm[off[x] .. off[x] + len[x]); off has n + 1 non-decreasing entries
+  // (off[n] = end of the data = nbytes), rows do not overlap, gaps between them are allowed.  The constructors take rows
+  // back to back (include/epihip.h) and fill `len` from the offsets; epi_batch_realign (layout.hip) replaces xm / off by
+  // the batch's own POSITION-CONGRUENT copy: off[x] = start[x] (mod 16), so that the position-aligned 16-byte chunks the
+  // tile kernels request are address-aligned (byte-misaligned dwordx4 loads run at ~0.85 of the rate).
   const uint8_t *xm = nullptr;
   const int64_t *off = nullptr;
+  const int32_t *len = nullptr;
   const int32_t *rname = nullptr, *strand = nullptr, *start = nullptr;
   bool owns = false;
-  epi::DevBuf own_xm, own_off, own_rname, own_strand, own_start;
+  int congruent = 0;         // 0: rows as the caller laid them out; 4 / 16: off[x] = start[x] modulo this
+  epi::DevBuf own_xm, own_off, own_len, own_rname, own_strand, own_start;
 
   // reusable workspace
   epi::DevBuf stats;        // RowStats of the batch (k_row_stats, queued once at creation)
@@ -214,6 +227,13 @@ int scan_block_sums_inplace(uint32_t *d_bsum, int64_t nb, uint32_t *d_total, hip
 int launch_row_stats(epi_batch *b, hipStream_t s);
 // host copy of the statistics (waits for the kernel whatever stream it was queued on); no validation
 int fetch_row_stats(epi_batch *b, hipStream_t s);
+// layout.hip: the batch's own position-congruent copy of xm (see epi_batch); `modulus` 4 or 16
+int realign_batch(epi_batch *b, int modulus, hipStream_t s);
+int layout_offsets(epi_batch *b, int modulus, hipStream_t s, DevBuf *new_off, unsigned long long *h_end, uint32_t *head);
+int layout_group(int64_t nbytes, int64_t n);
+// rows [row_a, row_a + nrows): their bytes inside source bytes [c0, c1) (src[0] = source byte c0) to their place in dst
+int layout_copy_range(const uint8_t *src, int64_t c0, int64_t c1, const int64_t *src_off, const int32_t *len, const int64_t *dst_off,
+                      int64_t row_a, int64_t nrows, int g, uint8_t *dst, hipStream_t s);
 // row statistics (validated: errors for bad offsets/strands/unsorted rows) + tile table; one host sync
 // `hinted` (may be null): the caller accepts a tile count remembered from an earlier call on this batch and tile size
 // (no host round trip in the middle of the index build) and verifies it against misc[0] at its own synchronisation.
@@ -228,6 +248,8 @@ struct Options {
   int cx_walk = 0;           // EPIHIP_CX_WALK=K     timing builds with -DEPI_CX_WALK_BUILD only: K consecutive tiles per workgroup of the lean CX kernel
   int heavy_rows = 0;        // EPIHIP_HEAVY_ROWS    candidate rows above which a tile is split / set aside (0: default)
   int tile_hint = 1;         // EPIHIP_TILE_HINT=0   tile index counted and scanned by every call
+  int realign = 16;          // EPIHIP_REALIGN=0/4/16  epi_batch_upload / epi_batch_realign: keep the rows back to back / start them at
+                             //                      offsets congruent to their start position modulo 4 / 16 (layout.hip)
   int mhl_fused = 1;         // EPIHIP_MHL_FUSED=0   two-kernel lMHL path for every batch
   int mhl_slot = -1;         // EPIHIP_MHL_SLOT
   int mhl_wg = 0;            // EPIHIP_MHL_WG        256 / 512 (two-kernel path)

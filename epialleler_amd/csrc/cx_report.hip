@@ -870,7 +870,7 @@ __device__ __forceinline__ bool cx2_tile(const Cx2Args &a, int tile, const Tile 
       __syncthreads();
       bool deep = false;
       for (int x = td.row_lo + (int)L.tid; x + CX_FLUSH_ROWS < td.row_hi; x += WG)
-        deep |= (int64_t)a.c.start[x + CX_FLUSH_ROWS] < (int64_t)a.c.start[x] + (a.c.off[x + 1] - a.c.off[x]);
+        deep |= (int64_t)a.c.start[x + CX_FLUSH_ROWS] < (int64_t)a.c.start[x] + a.c.len[x];
       if (deep) *s_flag = 1;
       __syncthreads();
       if (*s_flag) {
@@ -1543,7 +1543,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   if (lean && np == 1 && (grp >> 3) == 4 && (grp & 7) <= 5 && (int64_t)st.max_len + (CX_CH - 1) <= CX_PAD && options().cx_walk > 0)
     a.walk = options().cx_walk > 64 ? 64 : options().cx_walk;
 #endif
-  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
+  a.c.xm = b->xm; a.c.off = b->off; a.c.len = b->len; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = fused ? nullptr : d_pass;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;                   // (both batch constructors guarantee this much)
   a.tiles = b->tiles.as<Tile>();
   a.cursor = cursor;

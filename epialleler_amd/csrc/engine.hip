@@ -1,6 +1,7 @@
 // Engine plumbing: errors, device buffers, engine/batch lifetime, pinned
 // double-buffered upload, small synchronous read-backs, HIP-event profiling.
 #include "common.hpp"
+#include <algorithm>
 #include <sys/mman.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -126,6 +127,7 @@ int epi_engine_create(int device, epi_engine **out) {
   eng->device = device;
   EPI_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
   EPI_HIP(hipStreamCreateWithFlags(&eng->copy_stream, hipStreamNonBlocking));
+  EPI_HIP(hipStreamCreateWithFlags(&eng->aux_stream, hipStreamNonBlocking));
   EPI_HIP(hipHostMalloc(reinterpret_cast<void **>(&eng->h_scalars), 512, hipHostMallocDefault));
   *out = eng;
   return EPI_OK;
@@ -138,7 +140,13 @@ void epi_engine_destroy(epi_engine *e) {
     if (e->pinned[i]) (void)hipHostFree(e->pinned[i]);
     if (e->pinned_done[i]) (void)hipEventDestroy(e->pinned_done[i]);
   }
+  for (int i = 0; i < 2; i++) {
+    if (e->dev_stage[i]) (void)hipFree(e->dev_stage[i]);
+    if (e->up_done[i]) (void)hipEventDestroy(e->up_done[i]);
+    if (e->stage_free[i]) (void)hipEventDestroy(e->stage_free[i]);
+  }
   if (e->h_scalars) (void)hipHostFree(e->h_scalars);
+  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   delete e;
@@ -255,6 +263,68 @@ static int staged_upload(epi_engine *eng, void *d_dst, const void *h_src, size_t
   return EPI_OK;                                           // (the caller synchronises the copy stream once, after all columns)
 }
 
+// The packed bytes of an upload, laid out position-congruently while they arrive (layout.hip): the source arena crosses the
+// link in pieces of 64 MB into two device-side staging pieces; as soon as a piece is there, a kernel on aux_stream moves the
+// rows (and parts of rows) it holds to their places in the batch's arena while the next piece is on the link.  What the
+// layout costs an upload is the last piece's kernel -- not a second pass over the arena, and no second arena.
+static int upload_rows_congruent(epi_engine *eng, const uint8_t *h_xm, const int64_t *h_off, int64_t n, int64_t nbytes,
+                                 const int64_t *d_src_off, const int32_t *d_len, const int64_t *d_dst_off, uint8_t *arena) {
+  const bool pinned_src = is_pinned_host(h_xm);
+  // piece size: a pageable source goes through the engine's 64 MB pinned buffers; a pinned one is read by the DMA engine
+  // directly, in an eighth of the arena at a time (16 .. 256 MB: ~17 us of gap per piece on the link)
+  size_t chunk = 64u << 20;
+  if (pinned_src) {
+    chunk = ((size_t)nbytes / 8 + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+    if (chunk < (16u << 20)) chunk = 16u << 20;
+    if (chunk > (256u << 20)) chunk = 256u << 20;
+  }
+  if (eng->dev_stage_bytes < chunk) {
+    for (int i = 0; i < 2; i++) {
+      if (eng->dev_stage[i]) { EPI_HIP(hipFree(eng->dev_stage[i])); eng->dev_stage[i] = nullptr; }
+      EPI_HIP(hipMalloc(&eng->dev_stage[i], chunk));
+    }
+    eng->dev_stage_bytes = chunk;
+  }
+  for (int i = 0; i < 2; i++) {
+    if (!eng->up_done[i]) EPI_HIP(hipEventCreateWithFlags(&eng->up_done[i], hipEventDisableTiming));
+    if (!eng->stage_free[i]) EPI_HIP(hipEventCreateWithFlags(&eng->stage_free[i], hipEventDisableTiming));
+  }
+  if (!pinned_src && !eng->pinned[0]) {
+    for (int i = 0; i < 2; i++) {
+      EPI_HIP(hipHostMalloc(&eng->pinned[i], 64u << 20, hipHostMallocDefault));
+      EPI_HIP(hipEventCreateWithFlags(&eng->pinned_done[i], hipEventDisableTiming));
+    }
+    eng->pinned_bytes = 64u << 20;
+  }
+  if (!pinned_src) for (int i = 0; i < 2; i++) EPI_HIP(hipEventSynchronize(eng->pinned_done[i]));
+  const int g = layout_group(nbytes, n);
+  int k = 0;
+  for (int64_t c0 = 0; c0 < nbytes; k ^= 1) {
+    const int64_t c1 = nbytes - c0 < (int64_t)chunk ? nbytes : c0 + (int64_t)chunk;
+    const void *src = h_xm + c0;
+    if (!pinned_src) {
+      EPI_HIP(hipEventSynchronize(eng->pinned_done[k]));   // host buffer k drained
+      parallel_memcpy(eng->pinned[k], src, (size_t)(c1 - c0));
+      src = eng->pinned[k];
+    }
+    EPI_HIP(hipStreamWaitEvent(eng->copy_stream, eng->stage_free[k], 0));   // the kernel that emptied device piece k two pieces ago
+    EPI_HIP(hipMemcpyAsync(eng->dev_stage[k], src, (size_t)(c1 - c0), hipMemcpyHostToDevice, eng->copy_stream));
+    if (!pinned_src) EPI_HIP(hipEventRecord(eng->pinned_done[k], eng->copy_stream));
+    EPI_HIP(hipEventRecord(eng->up_done[k], eng->copy_stream));
+    // rows with a byte, or their end, in (c0, c1]: from the first row that ends behind c0 (every row in the first piece) to the
+    // last one that starts at or before c1 (the kernel clips; a row that only touches c1 does nothing)
+    const int64_t ra = c0 == 0 ? 0 : (std::upper_bound(h_off + 1, h_off + n + 1, c0) - (h_off + 1));
+    const int64_t rb = (std::upper_bound(h_off, h_off + n, c1) - h_off) - 1;
+    EPI_HIP(hipStreamWaitEvent(eng->aux_stream, eng->up_done[k], 0));
+    if (rb >= ra)
+      EPI_TRY(layout_copy_range(static_cast<const uint8_t *>(eng->dev_stage[k]), c0, c1, d_src_off, d_len, d_dst_off, ra, rb - ra + 1, g, arena,
+                                eng->aux_stream));
+    EPI_HIP(hipEventRecord(eng->stage_free[k], eng->aux_stream));
+    c0 = c1;
+  }
+  return EPI_OK;
+}
+
 }  // extern "C"
 
 namespace epi {
@@ -355,32 +425,61 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const
   b->nbytes = nbytes;
   b->owns = true;
   int rc = EPI_OK;
+  const int modulus = (n > 0 && nbytes > 0) ? options().realign : 0;   // EPIHIP_REALIGN=0: rows stay as uploaded
+  DevBuf new_off;
   do {
-    const size_t cap = ((size_t)nbytes + 15) / 16 * 16 + 64;
-    if ((rc = b->own_xm.ensure(cap))) break;
     if ((rc = b->own_off.ensure((size_t)(n + 1) * 8))) break;
     if ((rc = b->own_rname.ensure((size_t)n * 4 + 4))) break;
     if ((rc = b->own_strand.ensure((size_t)n * 4 + 4))) break;
     if ((rc = b->own_start.ensure((size_t)n * 4 + 4))) break;
-    if (hipMemsetAsync(static_cast<char *>(b->own_xm.p) + nbytes, 0xFB, cap - nbytes, e->copy_stream) != hipSuccess) {
-      rc = fail(EPI_ERR_HIP, "memset failed"); break;
-    }
-    if (nbytes && (rc = staged_upload(e, b->own_xm.p, xm, (size_t)nbytes))) break;
     if ((rc = staged_upload(e, b->own_off.p, off, (size_t)(n + 1) * 8))) break;
     if (n) {
       if ((rc = staged_upload(e, b->own_rname.p, rname, (size_t)n * 4))) break;
       if ((rc = staged_upload(e, b->own_strand.p, strand, (size_t)n * 4))) break;
       if ((rc = staged_upload(e, b->own_start.p, start, (size_t)n * 4))) break;
     }
-    if (hipStreamSynchronize(e->copy_stream) != hipSuccess) { rc = fail(EPI_ERR_HIP, "upload failed: %s", hipGetErrorName(hipGetLastError())); break; }
+    b->off = b->own_off.as<int64_t>();
+    b->rname = b->own_rname.as<int32_t>();
+    b->strand = b->own_strand.as<int32_t>();
+    b->start = b->own_start.as<int32_t>();
+    // row lengths and statistics behind the columns, on the copy stream (the first report reads the verdict)
+    if ((rc = launch_row_stats(b, e->copy_stream))) break;
+    if (modulus) {
+      // The batch owns its arena: rows go where the tile kernels read them fastest -- at offsets congruent to their start
+      // position (layout.hip) -- while the bytes arrive.  The offsets need the columns only.
+      unsigned long long h_end = 0;
+      uint32_t head = 0;
+      if ((rc = layout_offsets(b, modulus, e->copy_stream, &new_off, &h_end, &head))) break;
+      const size_t cap = ((size_t)h_end + 15) / 16 * 16 + 64;
+      if ((rc = b->own_xm.ensure(cap))) break;
+      uint8_t *arena = b->own_xm.as<uint8_t>();
+      if ((head && hipMemsetAsync(arena, 0xFB, head, e->aux_stream) != hipSuccess) ||
+          hipMemsetAsync(arena + h_end, 0xFB, cap - (size_t)h_end, e->aux_stream) != hipSuccess) { rc = fail(EPI_ERR_HIP, "memset failed"); break; }
+      if ((rc = upload_rows_congruent(e, xm, off, n, nbytes, b->off, b->len, new_off.as<int64_t>(), arena))) break;
+      if (hipStreamSynchronize(e->copy_stream) != hipSuccess || hipStreamSynchronize(e->aux_stream) != hipSuccess) {
+        rc = fail(EPI_ERR_HIP, "upload failed: %s", hipGetErrorName(hipGetLastError())); break;
+      }
+      std::swap(b->own_off, new_off);
+      b->off = b->own_off.as<int64_t>();
+      b->nbytes = (int64_t)h_end;
+      b->congruent = modulus;
+    } else {
+      const size_t cap = ((size_t)nbytes + 15) / 16 * 16 + 64;
+      if ((rc = b->own_xm.ensure(cap))) break;
+      if (hipMemsetAsync(static_cast<char *>(b->own_xm.p) + nbytes, 0xFB, cap - nbytes, e->copy_stream) != hipSuccess) {
+        rc = fail(EPI_ERR_HIP, "memset failed"); break;
+      }
+      if (nbytes && (rc = staged_upload(e, b->own_xm.p, xm, (size_t)nbytes))) break;
+      if (hipStreamSynchronize(e->copy_stream) != hipSuccess) { rc = fail(EPI_ERR_HIP, "upload failed: %s", hipGetErrorName(hipGetLastError())); break; }
+    }
   } while (0);
-  if (rc) { epi_batch_free(b); return rc; }
+  new_off.release();
+  if (rc) {
+    (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(e->aux_stream);   // nothing of the batch is in flight when it goes
+    epi_batch_free(b);
+    return rc;
+  }
   b->xm = b->own_xm.as<uint8_t>();
-  b->off = b->own_off.as<int64_t>();
-  b->rname = b->own_rname.as<int32_t>();
-  b->strand = b->own_strand.as<int32_t>();
-  b->start = b->own_start.as<int32_t>();
-  if ((rc = launch_row_stats(b, nullptr))) { epi_batch_free(b); return rc; }
   *out = b;
   return EPI_OK;
 }
@@ -419,7 +518,7 @@ int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int
 void epi_batch_free(epi_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->eng->device);
-  DevBuf *bufs[] = {&b->own_xm, &b->own_off, &b->own_rname, &b->own_strand, &b->own_start, &b->stats,
+  DevBuf *bufs[] = {&b->own_xm, &b->own_off, &b->own_len, &b->own_rname, &b->own_strand, &b->own_start, &b->stats,
                     &b->scan_tmp, &b->tiles, &b->tile_nrow, &b->tile_base,
                     &b->tile_out, &b->pool_key, &b->pool_a, &b->pool_b, &b->pool_c, &b->pool_d, &b->pool_e, &b->pool_f,
                     &b->misc, &b->mhl_m, &b->mhl_h, &b->mhl_blk, &b->mhl_cont, &b->mhl_cur, &b->d_shared_keys, &b->d_shared_owned, &b->heavy_list, &b->heavy_slab, &b->heavy_sums, &b->deep_list, &b->mhlf_fold_slab, &b->diag, &b->d_slot_tile, &b->pass_tmp, &b->thr_tab, &b->mhl_keep_tab, &b->host_io, &b->tile_bsum[0], &b->tile_bsum[1], &b->tile_bsum[2], &b->tile_bsum[3], &b->own_slab, &b->own_slab2};

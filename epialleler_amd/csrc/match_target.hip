@@ -11,7 +11,7 @@ constexpr int MT_CHUNK = 1024;
 
 template <bool CAPTURE>
 __global__ __launch_bounds__(256) void k_match_target(const int32_t *__restrict__ rname, const int32_t *__restrict__ start,
-                                                       const int64_t *__restrict__ off, int64_t n,
+                                                       const int32_t *__restrict__ len, int64_t n,
                                                        const int32_t *__restrict__ b_chr, const int32_t *__restrict__ b_start,
                                                        const int32_t *__restrict__ b_end, int32_t nbed, int32_t param,
                                                        int32_t *__restrict__ out) {
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_match_target(const int32_t *__restrict_
   if (valid) {
     chr = rname[x];
     rs = start[x];
-    re = rs + (int32_t)(off[x + 1] - off[x]) - 1;             // :34 / :67
+    re = rs + len[x] - 1;                                     // :34 / :67
   }
   int32_t res = INT32_MIN;                                    // NA_INTEGER
   bool done = !valid;
@@ -61,10 +61,10 @@ extern "C" int epi_batch_match_target_dev(epi_batch *b, const int32_t *d_bed_chr
   hipStream_t s = pick_stream(b, stream);
   const unsigned nb = (unsigned)((b->n + 255) / 256);
   if (capture)
-    hipLaunchKernelGGL((k_match_target<true>), dim3(nb), dim3(256), 0, s, b->rname, b->start, b->off, b->n, d_bed_chr,
+    hipLaunchKernelGGL((k_match_target<true>), dim3(nb), dim3(256), 0, s, b->rname, b->start, b->len, b->n, d_bed_chr,
                        d_bed_start, d_bed_end, nbed, param, d_match_out);
   else
-    hipLaunchKernelGGL((k_match_target<false>), dim3(nb), dim3(256), 0, s, b->rname, b->start, b->off, b->n, d_bed_chr,
+    hipLaunchKernelGGL((k_match_target<false>), dim3(nb), dim3(256), 0, s, b->rname, b->start, b->len, b->n, d_bed_chr,
                        d_bed_start, d_bed_end, nbed, param, d_match_out);
   EPI_HIP(hipGetLastError());
   return EPI_OK;

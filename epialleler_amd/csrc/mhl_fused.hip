@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_mhl_keep_table(double max_oo, int32_t n
 
 struct MhlFArgs {
   const uint8_t *xm;
-  const int64_t *off;
+  const int64_t *off;                     // row r owns xm[off[r] .. off[r] + len[r]); n + 1 non-decreasing offsets
+  const int32_t *len;
   const int32_t *start, *strand;
   int64_t xm_cap;                         // readable bytes behind xm
   const Tile *tiles;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
     int32_t n_st = 0, n_sd = 1;
     auto load_cols = [&](int rr) {
       n_rs = 0; n_re = 0; n_st = 0; n_sd = 1;
-      if (rr < bhi) { n_rs = a.off[rr]; n_re = a.off[rr + 1]; n_st = a.start[rr]; n_sd = a.strand[rr]; }
+      if (rr < bhi) { n_rs = a.off[rr]; n_re = n_rs + a.len[rr]; n_st = a.start[rr]; n_sd = a.strand[rr]; }
     };
     struct Geo { int32_t rel, len, sd; bool valid; };
     auto geo_of = [&](int rr) { Geo g; g.rel = (int32_t)((uint32_t)n_st - (uint32_t)td.pos0); g.len = (int32_t)(n_re - n_rs); g.sd = n_sd; g.valid = rr < bhi; return g; };
@@ -990,7 +991,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
   }
   MhlFArgs a{};
   memset(&a, 0, sizeof(a));
-  a.xm = b->xm; a.off = b->off; a.start = b->start; a.strand = b->strand;
+  a.xm = b->xm; a.off = b->off; a.len = b->len; a.start = b->start; a.strand = b->strand;
   a.xm_cap = (b->nbytes + 15) / 16 * 16;
   a.k7 = k * 0x01010101u;
   a.lut2 = make_mhlf_lut2(ctx_mask);

@@ -45,7 +45,8 @@ struct MhlRec { uint32_t first, last, m; };       // bytes [first,last] of the r
 
 struct RowsArgs {
   const uint8_t *xm;
-  const int64_t *off;
+  const int64_t *off;                     // row r owns xm[off[r] .. off[r] + len[r])
+  const int32_t *len;
   int64_t n;
   MhlLut lut;
   int32_t hmin;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows(RowsArgs a) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
   const bool valid = row < a.n;
   int64_t rs = 0, re = 0;
-  if (valid) { rs = a.off[row]; re = a.off[row + 1]; }
+  if (valid) { rs = a.off[row]; re = rs + a.len[row]; }
   const int64_t g0 = ((rs >> 4) << 4) + (int64_t)sub * W;     // the read starts somewhere in lane 0's first 16 bytes
   const Chunk<M> c = mhl_chunk<C>(a.xm, g0, g0 < re, rs, re, a.lut);
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_mhl_rows_multi(RowsArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n) return;
-  const int64_t rs = a.off[row], re = a.off[row + 1];
+  const int64_t rs = a.off[row], re = rs + a.len[row];
   const int64_t c0 = rs >> 5;
   const int64_t c1 = re > rs ? (re + 31) >> 5 : c0;
   const int64_t nblk = (c1 - c0 + 63) >> 6;
@@ -1022,7 +1023,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   unsigned long long *rec_max = reinterpret_cast<unsigned long long *>(b->misc.as<uint32_t>() + 12);   // misc[12..13]
 
   RowsArgs ra;
-  ra.xm = b->xm; ra.off = b->off; ra.n = b->n;
+  ra.xm = b->xm; ra.off = b->off; ra.len = b->len; ra.n = b->n;
   ra.lut = make_mhl_lut(ctx_mask);
   ra.hmin = (int32_t)hmin; ra.max_oo = max_ooctx_meth_frac;
   ra.rowinfo = b->mhl_h.as<int4>();
@@ -1037,7 +1038,7 @@ int epi_batch_mhl_report_dev(epi_batch *b, const char *ctx, int hmax, int hmin, 
   uint32_t *cursor = b->misc.as<uint32_t>() + 1;
 
   MhlArgs a;
-  a.c.xm = b->xm; a.c.off = b->off; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = nullptr;
+  a.c.xm = b->xm; a.c.off = b->off; a.c.len = b->len; a.c.start = b->start; a.c.strand = b->strand; a.c.pass = nullptr;
   a.rowinfo = b->mhl_h.as<int4>();
   a.blkrec = b->mhl_blk.as<uint2>();
   a.multi = multi ? 1 : 0;

@@ -20,7 +20,8 @@ namespace epi {
 
 struct PatArgs {
   const uint8_t *xm;
-  const int64_t *off;
+  const int64_t *off;             // row x owns xm[off[x] .. off[x] + len[x])
+  const int32_t *len;
   const int32_t *rname, *strand, *start;
   int64_t n;
   uint32_t target_rname, target_start, target_end, reverse_offset;
@@ -36,7 +37,7 @@ __device__ __forceinline__ PatSpan pat_span(const PatArgs &a, int64_t x) {
   PatSpan s;
   s.ok = false; s.start_x = 0; s.begin_i = 0; s.end_i = 0; s.offset_x = 0;
   if (a.rname[x] != (int32_t)a.target_rname) return s;                      // :78
-  const uint32_t size_x = (uint32_t)(a.off[x + 1] - a.off[x]);
+  const uint32_t size_x = (uint32_t)a.len[x];
   const uint32_t start_x = (uint32_t)a.start[x];
   const uint32_t end_x = start_x + size_x - 1u;
   const uint32_t over_start = start_x > a.target_start ? start_x : a.target_start;
@@ -155,7 +156,7 @@ int epi_batch_extract_patterns(epi_batch *b, int32_t target_rname, int32_t targe
   const int64_t lmax = b->h_stats.max_len;
 
   PatArgs a;
-  a.xm = b->xm; a.off = b->off; a.rname = b->rname; a.strand = b->strand; a.start = b->start; a.n = b->n;
+  a.xm = b->xm; a.off = b->off; a.len = b->len; a.rname = b->rname; a.strand = b->strand; a.start = b->start; a.n = b->n;
   a.target_rname = (uint32_t)target_rname; a.target_start = (uint32_t)target_start; a.target_end = (uint32_t)target_end;
   a.reverse_offset = (uint32_t)reverse_offset; a.min_overlap = min_overlap; a.clip = clip ? 1 : 0;
   a.ctx_mask = 0;

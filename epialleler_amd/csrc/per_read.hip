@@ -67,13 +67,13 @@ __device__ __forceinline__ uint32_t byte_range_mask(int64_t lo, int64_t hi) {
 
 template <int G, int NCLS, bool BETA>
 __global__ __launch_bounds__(256) void k_per_read(const uint8_t *__restrict__ xm, const int64_t *__restrict__ off,
-                                                   int64_t n, Luts L, ThrParams prm, int32_t *__restrict__ pass_out,
+                                                   const int32_t *__restrict__ len, int64_t n, Luts L, ThrParams prm, int32_t *__restrict__ pass_out,
                                                    double *__restrict__ beta_out) {
   const int sub = threadIdx.x & (G - 1);
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
   const bool valid = row < n;
   int64_t rs = 0, re = 0;
-  if (valid) { rs = off[row]; re = off[row + 1]; }
+  if (valid) { rs = off[row]; re = rs + len[row]; }
   const int64_t c0 = rs >> 4;
   const int64_t c1 = re > rs ? (re + 15) >> 4 : c0;
   uint32_t acc[NCLS];
@@ -187,7 +187,7 @@ template <int RPG> constexpr int pw_waves() { return RPG >= 4 ? 5 : (RPG == 3 ? 
 
 template <int G, int RPG, bool BETA>
 __global__ __launch_bounds__(256, (pw_waves<RPG>())) void k_per_read_wide(const uint8_t *__restrict__ xm, const int64_t *__restrict__ off,
-                                                                            int64_t n, ClassLut F, ThrParams prm,
+                                                                            const int32_t *__restrict__ rlen, int64_t n, ClassLut F, ThrParams prm,
                                                                             int32_t *__restrict__ pass_out, double *__restrict__ beta_out) {
   constexpr int RW = 64 / G;                            // lane groups per wavefront
   const int sub = threadIdx.x & (G - 1);
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256, (pw_waves<RPG>())) void k_per_read_wide(const 
   for (int q = 0; q < RPG; q++) {
     const int64_t row = row0 + (int64_t)q * RW;
     const int64_t rc = row < n ? row : n - 1;           // every lane loads (the count of loads in flight stays static)
-    const int64_t o0 = off[rc], o1 = off[rc + 1];
+    const int64_t o0 = off[rc];
     rel[q] = (int)(o0 & 15);
-    len[q] = row < n ? (int)(o1 - o0) : 0;
+    len[q] = row < n ? rlen[rc] : 0;
     nch[q] = len[q] > 0 ? (rel[q] + len[q] + 15) >> 4 : 0;
     base[q] = nch[q] > 0 ? xm + (o0 & ~(int64_t)15) : xm;
   }
@@ -343,7 +343,7 @@ static int launch_per_read_wide(epi_batch *b, const ClassLut &F, const ThrParams
   const unsigned nb = (unsigned)((b->n + rows_per_wg - 1) / rows_per_wg);
   const char *pname = BETA ? "xm_beta" : "threshold";
   prof_begin(pname, s);
-#define EPI_PW(GG, RR) hipLaunchKernelGGL((k_per_read_wide<GG, RR, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->n, F, prm, d_pass, d_beta)
+#define EPI_PW(GG, RR) hipLaunchKernelGGL((k_per_read_wide<GG, RR, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->len, b->n, F, prm, d_pass, d_beta)
 #define EPI_PW_G(RR)                                                                   \
   switch (g) { case 8: EPI_PW(8, RR); break; case 16: EPI_PW(16, RR); break; case 32: EPI_PW(32, RR); break; default: EPI_PW(64, RR); break; }
   if (g == 2) EPI_PW(2, 2);
@@ -373,7 +373,7 @@ static int launch_per_read(epi_batch *b, const Luts &L, const ThrParams &prm, in
   prof_begin(pname, s);
 #define EPI_LAUNCH(GG)                                                                                         \
   case GG:                                                                                                     \
-    hipLaunchKernelGGL((k_per_read<GG, NCLS, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->n, L, prm,   \
+    hipLaunchKernelGGL((k_per_read<GG, NCLS, BETA>), dim3(nb), dim3(256), 0, s, b->xm, b->off, b->len, b->n, L, prm,   \
                        d_pass, d_beta);                                                                        \
     break;
   switch (g) {

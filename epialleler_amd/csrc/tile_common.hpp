@@ -27,7 +27,8 @@ constexpr int kCxGuard = 4;               // dwords of LDS padding around the co
 
 struct RowCols {                          // the batch columns a tile kernel reads
   const uint8_t *xm;
-  const int64_t *off;
+  const int64_t *off;                     // row r owns xm[off[r] .. off[r] + len[r])
+  const int32_t *len;
   const int32_t *start, *strand, *pass;   // pass may be null (all TRUE)
 };
 
@@ -56,7 +57,7 @@ __device__ __forceinline__ RowVals cx_load_row(const RowCols &a, const Tile &td,
   if (v.ok) {
     v.st = a.start[r];
     v.o = a.off[r];
-    v.len = (int32_t)((uint32_t)a.off[r + 1] - (uint32_t)v.o);   // < 2^31 (checked by k_row_stats)
+    v.len = a.len[r];                     // >= 0, start + len < 2^31 (k_row_stats)
     v.sd = a.strand[r];
     v.ps = a.pass ? a.pass[r] : 1;
   }

@@ -21,13 +21,14 @@ __device__ __forceinline__ int64_t tile_of(int64_t pos, int32_t sh) { return (po
 
 __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                     const int32_t *__restrict__ strand, const int64_t *__restrict__ off,
-                                                    int64_t n, RowStats *__restrict__ st) {
+                                                    int64_t n, RowStats *__restrict__ st, int32_t *__restrict__ len_out) {
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int len = 0, unsorted = 0, bad_strand = 0, bad_len = 0, deep = 0;
   if (x < n) {
-    const int64_t l = off[x + 1] - off[x];
+    const int64_t l = off[x + 1] - off[x];                  // (the constructors take rows back to back)
     const int32_t s0 = start[x];
     if (l < 0 || (int64_t)s0 + l > 0x7FFFFFFFLL) bad_len = 1; else len = (int)l;
+    len_out[x] = len;                                       // the row lengths every later kernel reads (0 for a bad row: the first report raises the error)
     const int32_t sd = strand[x];
     if (sd != 1 && sd != 2 && l != 0) bad_strand = 1;       // (an empty row may carry strand 0: the placeholder template the
                                                             // reference pushes for a paired-end file without a usable pair,
@@ -216,10 +217,13 @@ static int log2_tile(int32_t T) {
 // Row statistics are a property of the (immutable) batch: queued once, when the batch is created.
 int launch_row_stats(epi_batch *b, hipStream_t s) {
   EPI_TRY(b->stats.ensure(sizeof(RowStats)));
+  EPI_TRY(b->own_len.ensure((size_t)b->n * 4 + 4));
+  b->len = b->own_len.as<int32_t>();
   EPI_HIP(hipMemsetAsync(b->stats.p, 0, sizeof(RowStats), s));
   if (b->n > 0) {
     const unsigned nb = (unsigned)((b->n + 255) / 256);
-    hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, b->stats.as<RowStats>());
+    hipLaunchKernelGGL(k_row_stats, dim3(nb), dim3(256), 0, s, b->start, b->rname, b->strand, b->off, b->n, b->stats.as<RowStats>(),
+                       b->own_len.as<int32_t>());
     EPI_HIP(hipGetLastError());
   }
   if (!b->stats_done) EPI_HIP(hipEventCreateWithFlags(&b->stats_done, hipEventDisableTiming));

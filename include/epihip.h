@@ -197,6 +197,20 @@ int epi_default_engine(epi_engine **out);
 int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int64_t nbytes,
                     const int64_t *d_off, const int32_t *d_rname, const int32_t *d_strand,
                     const int32_t *d_start, int64_t n, epi_batch **out);
+/* Position-congruent rows.  The tile kernels read position-aligned 16-byte chunks; with rows back to back those have
+ * any byte alignment and load at ~0.85 of the aligned rate.  epi_batch_realign gives the batch its OWN copy of xm in
+ * which row x starts at an offset = start[x] (mod 16) (<= 15 bytes of filler between rows, one pass over the bytes, one
+ * host synchronisation) -- the reference keeps one std::string per template (src/epialleleR.h:28-38), so where rows
+ * start is the engine's business.  epi_batch_upload does this itself; for an adopted batch it is the caller's call:
+ * afterwards the batch no longer reads d_xm / d_off (the caller may free them), and holds B + <= 15 n bytes of its own.
+ * Call it before the first report on the batch.  Results never depend on it.  EPIHIP_REALIGN=0 makes it a no-op
+ * (A/B runs); 4 = congruent modulo 4 only.  epi_batch_layout: 0 = as given, 4 / 16 = congruent modulo that. */
+int epi_batch_realign(epi_batch *b, void *stream);
+int epi_batch_layout(const epi_batch *b);
+/* The rows as the kernels read them: row x owns d_xm[d_off[x] .. d_off[x] + d_len[x]) (d_off: n + 1 non-decreasing
+ * entries, d_off[n] = *nbytes; d_len: n; written by a kernel queued on the null stream when the batch was created).
+ * Device pointers, valid until the batch is freed or realigned.  Any out-pointer may be NULL. */
+int epi_batch_view(const epi_batch *b, const uint8_t **d_xm, const int64_t **d_off, const int32_t **d_len, int64_t *nbytes);
 void epi_batch_free(epi_batch *b);
 int64_t epi_batch_nrows(const epi_batch *b);
 

@@ -116,6 +116,84 @@ __global__ __launch_bounds__(256) void k_stream(const uint8_t *__restrict__ xm, 
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+
+// position-aligned chunks as the CX tile kernel requests them: a row's chunk grid starts s = hash(row) % 16 bytes BEFORE the row
+// (addresses are not 16-byte aligned).  MIS = false: the same lanes, aligned addresses.
+struct __attribute__((packed, aligned(1))) U4m { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 ldm(const uint8_t *p) { const U4m v = *reinterpret_cast<const U4m *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int mis_of(int64_t row) { return (int)((row * 2654435761u >> 7) & 15); }
+constexpr int LS = 304;                            // 16-byte aligned row stride, as in a packed batch
+// shape C (4 lanes x 5 chunks, 16 rows per instruction, 64 contiguous bytes per row and instruction)
+template <bool MIS>
+__global__ __launch_bounds__(256) void k_c_pos(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(gid & 3);
+  const int64_t row = gid >> 2;
+  const int64_t a0 = 64 + row * LS - (MIS ? mis_of(row) : 0);
+  uint4 w[5];
+#pragma unroll
+  for (int u = 0; u < 5; u++) w[u] = row < n ? ldm(xm + a0 + (int64_t)(4 * u + j) * 16) : make_uint4(0, 0, 0, 0);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 5; u++) acc ^= fold(w[u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// pair shape: 8 lanes own rows (g, 8 + g) of a wavefront's 16: instructions 0, 1 read chunks 0-7 / 8-15 of row g (128 contiguous
+// bytes), instruction 2 chunks 16-19 of both rows (64 bytes each), instructions 3, 4 chunks 0-7 / 8-15 of row 8 + g.
+template <bool MIS>
+__global__ __launch_bounds__(256) void k_pair_pos(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(gid & 7), g = (int)((gid >> 3) & 7);
+  const int64_t wave = gid >> 6;
+  const int64_t ra = wave * 16 + g, rb = ra + 8;
+  const int64_t aa = 64 + ra * LS - (MIS ? mis_of(ra) : 0), ab = 64 + rb * LS - (MIS ? mis_of(rb) : 0);
+  uint4 w[5];
+  const bool oka = ra < n, okb = rb < n;
+  w[0] = oka ? ldm(xm + aa + (int64_t)j * 16) : make_uint4(0, 0, 0, 0);
+  w[1] = oka ? ldm(xm + aa + (int64_t)(8 + j) * 16) : make_uint4(0, 0, 0, 0);
+  { const bool lo = j < 4; const int64_t a = (lo ? aa : ab) + (int64_t)(16 + (j & 3)) * 16; w[2] = (lo ? oka : okb) ? ldm(xm + a) : make_uint4(0, 0, 0, 0); }
+  w[3] = okb ? ldm(xm + ab + (int64_t)j * 16) : make_uint4(0, 0, 0, 0);
+  w[4] = okb ? ldm(xm + ab + (int64_t)(8 + j) * 16) : make_uint4(0, 0, 0, 0);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 5; u++) acc ^= fold(w[u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// 8 lanes x 3 chunks (24 slots for 20 chunks), 8 rows per instruction, 128 contiguous bytes
+template <bool MIS>
+__global__ __launch_bounds__(256) void k_b_pos(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(gid & 7);
+  const int64_t row = gid >> 3;
+  const int64_t a0 = 64 + row * LS - (MIS ? mis_of(row) : 0);
+  uint4 w[3];
+#pragma unroll
+  for (int u = 0; u < 3; u++) w[u] = (row < n && 8 * u + j < 20) ? ldm(xm + a0 + (int64_t)(8 * u + j) * 16) : make_uint4(0, 0, 0, 0);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 3; u++) acc ^= fold(w[u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// 16 lanes own FOUR rows (80 chunks = 16 x 5): every instruction reads 256 contiguous bytes of one row, or 64 of each of the four
+template <bool MIS>
+__global__ __launch_bounds__(256) void k_quad_pos(const uint8_t *__restrict__ xm, int64_t n, uint32_t *out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(gid & 15), g = (int)((gid >> 4) & 3);
+  const int64_t wave = gid >> 6;
+  uint4 w[5];
+  int64_t a[4]; bool ok[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int64_t r = wave * 16 + 4 * q + g; ok[q] = r < n; a[q] = 64 + r * LS - (MIS ? mis_of(r) : 0); }
+#pragma unroll
+  for (int q = 0; q < 4; q++) w[q] = ok[q] ? ldm(xm + a[q] + (int64_t)j * 16) : make_uint4(0, 0, 0, 0);
+  { const int q = j >> 2; const int64_t aq = q == 0 ? a[0] : q == 1 ? a[1] : q == 2 ? a[2] : a[3]; const bool k = q == 0 ? ok[0] : q == 1 ? ok[1] : q == 2 ? ok[2] : ok[3];
+    w[4] = k ? ldm(xm + aq + (int64_t)(16 + (j & 3)) * 16) : make_uint4(0, 0, 0, 0); }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int u = 0; u < 5; u++) acc ^= fold(w[u]);
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <class F> void timeit(const char *name, double bytes, F launch) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   launch(); launch();
@@ -129,8 +207,8 @@ template <class F> void timeit(const char *name, double bytes, F launch) {
 int main() {
   const int64_t n = 10000000, bytes = n * L;
   uint8_t *xm; uint32_t *out;
-  hipMalloc(&xm, bytes + 4096); hipMalloc(&out, 64);
-  hipMemset(xm, 0x5B, bytes + 4096);
+  hipMalloc(&xm, n * 304 + 8192); hipMalloc(&out, 64);
+  hipMemset(xm, 0x5B, n * 304 + 8192);
   auto grid = [&](int G, int RPG) { return (unsigned)((n / RPG * G + 255) / 256 + 64); };
   timeit("A  2 lanes x 10 loads, 1 row  (32 rows/instr, 32 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<2, 10, 1>), dim3(grid(2, 1)), dim3(256), 0, 0, xm, n, out); });
   timeit("B  8 lanes x 3 loads, 4 rows  (8 rows/instr, 128 B each)", bytes, [&] { hipLaunchKernelGGL((k_rows<8, 3, 4>), dim3(grid(8, 4)), dim3(256), 0, 0, xm, n, out); });
@@ -148,6 +226,18 @@ int main() {
   timeit("K3 8 lanes x 3 contiguous 16-byte loads per lane, unaligned", bytes, [&] { hipLaunchKernelGGL((k_rows_lane<8, 3, false>), dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
   timeit("M  4 lanes: 32 + 32 + 16 bytes per lane, 32-byte interleave, unaligned", bytes, [&] { hipLaunchKernelGGL((k_rows_32<false>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
   timeit("M2 the same, 16-byte aligned", bytes, [&] { hipLaunchKernelGGL((k_rows_32<true>), dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, xm, n, out); });
+  {
+    const int64_t nb = n * LS;
+    auto g4 = (unsigned)((n * 4 + 255) / 256), g8 = (unsigned)((n * 8 + 255) / 256);
+    timeit("PC  4x5, position grid, aligned", nb, [&] { hipLaunchKernelGGL((k_c_pos<false>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+    timeit("PCm 4x5, position grid, misaligned (CX kernel today)", nb, [&] { hipLaunchKernelGGL((k_c_pos<true>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+    timeit("PP  pairs: 8 lanes x 5 over two rows, aligned", nb, [&] { hipLaunchKernelGGL((k_pair_pos<false>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+    timeit("PPm pairs, misaligned", nb, [&] { hipLaunchKernelGGL((k_pair_pos<true>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+    timeit("PB  8x3 (24 slots), aligned", nb, [&] { hipLaunchKernelGGL((k_b_pos<false>), dim3(g8), dim3(256), 0, 0, xm, n, out); });
+    timeit("PBm 8x3, misaligned", nb, [&] { hipLaunchKernelGGL((k_b_pos<true>), dim3(g8), dim3(256), 0, 0, xm, n, out); });
+    timeit("PQ  quads: 16 lanes x 5 over four rows, aligned", nb, [&] { hipLaunchKernelGGL((k_quad_pos<false>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+    timeit("PQm quads, misaligned", nb, [&] { hipLaunchKernelGGL((k_quad_pos<true>), dim3(g4), dim3(256), 0, 0, xm, n, out); });
+  }
   const int64_t nch = bytes / 16;
   timeit("D  plain stream, 10 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<10>), dim3((unsigned)((nch / 10 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });
   timeit("D4 plain stream, 4 x 16 B per lane", bytes, [&] { hipLaunchKernelGGL((k_stream<4>), dim3((unsigned)((nch / 4 + 255) / 256 + 1)), dim3(256), 0, 0, xm, nch, out); });

@@ -21,6 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"EPIHIP_PR_WIDE": "0"},                                             # per-read kernels: the 2-lanes-per-read layout for every call
     {"EPIHIP_CX_SLOT": "0"},                                             # no slots: every tile through the cursor
     {"EPIHIP_TILE_HINT": "0"},                                           # tile index counted and scanned by every call (no remembered offsets)
+    {"EPIHIP_REALIGN": "0"},                                             # rows stay back to back (no position-congruent copy, layout.hip)
+    {"EPIHIP_REALIGN": "4"},                                             # ... congruent to their start position modulo 4 only
+    {"EPIHIP_REALIGN": "0", "EPIHIP_MHL_FUSED": "0", "EPIHIP_CX_LEAN": "0"},
     {"EPIHIP_CX_LEAN": "0"},                                             # single-context CX reports: the general kernel (u16 copy of the
                                                                          # u8 counters, folds) also where no position is deeper than 255 rows
     {"EPIHIP_CX_LEAN": "0", "EPIHIP_HEAVY_ROWS": "100", "EPIHIP_CX_SLOT": "3"},
