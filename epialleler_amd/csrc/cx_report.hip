@@ -376,6 +376,51 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
         }
       }
     }
+  } else if constexpr (NP == 1 && G >= 16) {
+    // One reported context, pass flags given, reads of more than ~600 bytes (16 and more lanes per row; measured: -5 % at
+    // 1.2 and 2.4 kb, -12 % at 10 kb, but +3 ... +10 % for the 4 x 5 shape of PE150 templates, which keeps the LUT below;
+    // profiles/r04_cx_experiments.txt): no byte LUT at all on the common path.  The codes of two dwords become the
+    // nibbles of one word; ((pk & 7..7) ^ k..k) + 7..7 leaves bit 3 of a nibble CLEAR iff the code is the context's in either
+    // case (k or k | 8), and the case bit of a code is its bit 3 -- plain two-operand VALU and three-input bit operations
+    // (2 cycles per wavefront on gfx950, where v_perm_b32 / v_and_or_b32 / compares take 4), and one test per PAIR of dwords
+    // instead of one per dword.  The rare codes -- skipped (11) and doubled (9), as is or after lower-casing (c | 8, :118,122:
+    // then also 3 and 1) -- are a masked compare of the same word: (c & 1101b) == 1001b, resp. (c & 0101b) == 0001b; a lane
+    // that holds one takes the LUT path below for its chunks.
+    const bool passing = g.ps != 0;
+    const uint32_t k77 = (a.ctx_of_plane & 255u) * 0x11111111u;
+    const uint32_t rm = passing ? 0xDDDDDDDDu : 0x55555555u, rv = passing ? 0x99999999u : 0x11111111u;
+    uint32_t clean = 0xFFFFFFFFu;                                     // bit 3 of every nibble stays set while no rare code was seen
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;      // (always: the visit stays inside the window)
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const uint32_t pk = (w[u][2 * e] & 0x0F0F0F0Fu) | ((w[u][2 * e + 1] << 4) & 0xF0F0F0F0u);
+        const uint32_t z = ((pk & 0x77777777u) ^ k77) + 0x77777777u;
+        const uint32_t np = ~z & 0x88888888u;                        // calls of the context: bit 3 of a byte = first dword, bit 7 = second
+        const uint32_t t = (pk & rm) ^ rv;
+        clean &= ((t & 0x77777777u) + 0x77777777u) | t;
+        if (np != 0u && inside && !(EPI_CX_ABLATE & 2)) {
+          const uint32_t up = passing ? np & ~pk : 0u;               // methylated calls of a passing read (a failed one is lower-cased)
+          const uint32_t n0 = (np >> 3) & 0x01010101u, n1 = (np >> 7) & 0x01010101u;
+          if (n0 != 0u) atomicAdd(nar + 4 * u * G + 2 * e, (unsigned long long)n0 | ((unsigned long long)((up >> 3) & 0x01010101u) << 32));
+          if (n1 != 0u) atomicAdd(nar + 4 * u * G + 2 * e + 1, (unsigned long long)n1 | ((unsigned long long)((up >> 7) & 0x01010101u) << 32));
+        }
+      }
+    }
+    if (__builtin_expect((~clean & 0x88888888u) != 0u, 0)) {
+      const uint32_t pick0 = passing ? 0u : 0x08080808u;
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const bool inside = (uint32_t)(cb + u * G) < (uint32_t)C;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t f = cx2_lut(w[u][d], a.lut_rx, pick0);
+          const uint32_t sk = (f >> 6) & 0x01010101u, db = (f >> 7) & 0x01010101u;
+          if ((sk | db) != 0u && inside) atomicAdd(cor + 4 * u * G + d, (unsigned long long)sk | ((unsigned long long)db << 32));
+        }
+      }
+    }
   } else {
     // calls of the reported contexts: one ds_add_u64 per dword and plane, only from lanes that hold a call
     const uint32_t pick0 = g.ps == 0 ? 0x08080808u : 0u;            // failed the threshold: lower-cased (:118)
