@@ -386,7 +386,8 @@ def layout_off(cx, wl, res, steps):
     finally:
         raw.close()
     return {"ms_per_step": round(ms, 4), "vs_congruent": round(ms / res["ms_per_step"], 3), "kernel_ms": round(m2.value / max(c2.value, 1), 4),
-            "what": "rows back to back (epi_batch_adopt without epi_batch_realign): chunk loads at any byte alignment"}
+            "what": "rows back to back (epi_batch_adopt without epi_batch_realign): chunk loads at any byte alignment, and the tile "
+                    "table rebuilt (verified) by every step because the columns stay the caller's"}
 
 
 def streamed_and_d2h(cx, wl, res):
@@ -676,7 +677,10 @@ def main():
                        "layout": ("rows at offsets congruent to their start position modulo %d in the engine's own copy of xm, made once per "
                                   "batch by epi_batch_realign (batch_ms below; layout_off: the step without it)" % res["layout"]) if res.get("layout")
                                  else "rows back to back as adopted",
-                       "batch_ms": round(res["batch_ms"], 3), "tile_index": "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block (EPIHIP_TILE_HINT=0: counted and scanned every step)", "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
+                       "batch_ms": round(res["batch_ms"], 3), "tile_index": ("the batch owns its columns (epi_batch_realign / epi_batch_upload): the tile table of the first report is kept, steps only reset its counters "
+                                      "(tile_hint_off: EPIHIP_TILE_HINT=0, counted, scanned and filled by every step)" if res.get("layout") else
+                                      "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block "
+                                      "(EPIHIP_TILE_HINT=0: counted and scanned every step)"), "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
                                     % ("RCCL, called by the library: epi_batch_*_report_sharded" if res.get("native_comm")
                                        else args.backend + " collectives of torch.distributed around the two-step C entry points"
                                        + (", a rehearsal without RCCL" if args.backend != "nccl" else ""),

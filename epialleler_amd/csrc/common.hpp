@@ -129,6 +129,7 @@ struct epi_batch {
   const int32_t *rname = nullptr, *strand = nullptr, *start = nullptr;
   bool owns = false;
   int congruent = 0;         // 0: rows as the caller laid them out; 4 / 16: off[x] = start[x] modulo this
+  bool cols_owned = false;   // every column is the batch's own copy (uploaded, or adopted and realigned): nobody can change a row
   epi::DevBuf own_xm, own_off, own_len, own_rname, own_strand, own_start;
 
   // reusable workspace
@@ -185,6 +186,11 @@ struct epi_batch {
   int32_t tile_hint_lmax[4] = {0, 0, 0, 0};
   epi::DevBuf tile_bsum[4];                  // ... and the scanned per-block tile counts of the index build
   int32_t last_tile = 0;    // tile size of the last CX report
+  // The tile table itself is a function of (rname, start, longest row, tile size, shared keys): while the batch owns its
+  // columns the table of the last build is still valid for the same tile size and keys, and build_tiles skips the pass.
+  int32_t tiles_T = 0, tiles_nt = 0, tiles_lmax = 0;
+  std::vector<int64_t> tiles_shared;
+  epi::DevBuf tiles_nt_dev;                  // the tile count as the index pass left it in misc[0]
 
   // multi-GPU shared tiles
   std::vector<int64_t> shared_keys;

@@ -480,6 +480,7 @@ int epi_batch_upload(epi_engine *e, const uint8_t *xm, const int64_t *off, const
     return rc;
   }
   b->xm = b->own_xm.as<uint8_t>();
+  b->cols_owned = true;
   *out = b;
   return EPI_OK;
 }
@@ -521,7 +522,7 @@ void epi_batch_free(epi_batch *b) {
   DevBuf *bufs[] = {&b->own_xm, &b->own_off, &b->own_len, &b->own_rname, &b->own_strand, &b->own_start, &b->stats,
                     &b->scan_tmp, &b->tiles, &b->tile_nrow, &b->tile_base,
                     &b->tile_out, &b->pool_key, &b->pool_a, &b->pool_b, &b->pool_c, &b->pool_d, &b->pool_e, &b->pool_f,
-                    &b->misc, &b->mhl_m, &b->mhl_h, &b->mhl_blk, &b->mhl_cont, &b->mhl_cur, &b->d_shared_keys, &b->d_shared_owned, &b->heavy_list, &b->heavy_slab, &b->heavy_sums, &b->deep_list, &b->mhlf_fold_slab, &b->diag, &b->d_slot_tile, &b->pass_tmp, &b->thr_tab, &b->mhl_keep_tab, &b->host_io, &b->tile_bsum[0], &b->tile_bsum[1], &b->tile_bsum[2], &b->tile_bsum[3], &b->own_slab, &b->own_slab2};
+                    &b->misc, &b->mhl_m, &b->mhl_h, &b->mhl_blk, &b->mhl_cont, &b->mhl_cur, &b->d_shared_keys, &b->d_shared_owned, &b->heavy_list, &b->heavy_slab, &b->heavy_sums, &b->deep_list, &b->mhlf_fold_slab, &b->diag, &b->d_slot_tile, &b->pass_tmp, &b->thr_tab, &b->mhl_keep_tab, &b->host_io, &b->tile_bsum[0], &b->tile_bsum[1], &b->tile_bsum[2], &b->tile_bsum[3], &b->own_slab, &b->own_slab2, &b->tiles_nt_dev};
   for (DevBuf *d : bufs) d->release();
   if (b->stats_done) (void)hipEventDestroy(b->stats_done);
   delete b;

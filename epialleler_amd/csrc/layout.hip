@@ -205,12 +205,27 @@ int realign_batch(epi_batch *b, int modulus, hipStream_t s) {
     if ((rc = layout_copy_range(b->xm, 0, INT64_MAX, b->off, b->len, new_off.as<int64_t>(), 0, b->n, layout_group(b->nbytes, b->n), dst, s))) break;
     // the old arena may be freed (an uploaded batch) or handed back to its owner (an adopted one) when this returns
     if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(EPI_ERR_HIP, "realign: %s", hipGetErrorName(hipGetLastError())); break; }
+    if (!b->owns) {
+      // an adopted batch: the three small columns become the batch's own as well -- from here on nobody else can change a
+      // row, and what is derived from the rows alone (the tile table, tiles.hip) stays valid between reports
+      const size_t cb = (size_t)b->n * 4;
+      if ((rc = b->own_rname.ensure(cb + 4)) || (rc = b->own_strand.ensure(cb + 4)) || (rc = b->own_start.ensure(cb + 4))) break;
+      if (hipMemcpyAsync(b->own_rname.p, b->rname, cb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(b->own_strand.p, b->strand, cb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(b->own_start.p, b->start, cb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { rc = fail(EPI_ERR_HIP, "realign: column copy failed"); break; }
+      b->rname = b->own_rname.as<int32_t>();
+      b->strand = b->own_strand.as<int32_t>();
+      b->start = b->own_start.as<int32_t>();
+      b->owns = true;
+    }
     std::swap(b->own_xm, new_xm);
     std::swap(b->own_off, new_off);
     b->xm = b->own_xm.as<uint8_t>();
     b->off = b->own_off.as<int64_t>();
     b->nbytes = (int64_t)h_end;
     b->congruent = modulus;
+    b->cols_owned = true;
   } while (0);
   new_off.release(); new_xm.release();                    // (after the swap: the batch's previous own buffers, if it had any)
   return rc;

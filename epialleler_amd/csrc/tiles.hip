@@ -208,6 +208,14 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_pass(const int32_t *__restr
   }
 }
 
+// what the index pass leaves in misc when the table itself is reused: the tile count and the report kernels' zeroed counters
+__global__ void k_misc_reset(uint32_t *__restrict__ misc, const uint32_t *__restrict__ nt) {
+  if (threadIdx.x == 0) {
+    misc[0] = nt[0];
+    misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; misc[5] = 0; misc[8] = 0;
+  }
+}
+
 static int log2_tile(int32_t T) {
   int sh = 0;
   while ((1 << sh) < T) sh++;
@@ -266,6 +274,23 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   int slot = -1;
   for (int i = 0; i < 4; i++) if (b->tile_hint_T[i] == T) slot = i;
   const int use_hint = options().tile_hint;                // EPIHIP_TILE_HINT=0: every call counts, scans and asks (A/B runs, tests)
+  auto remember_table = [&](uint32_t nt) -> int {            // (after the pass that filled b->tiles)
+    b->tiles_T = 0;
+    if (!b->cols_owned) return EPI_OK;
+    EPI_TRY(b->tiles_nt_dev.ensure(4));
+    EPI_HIP(hipMemcpyAsync(b->tiles_nt_dev.p, d_misc, 4, hipMemcpyDeviceToDevice, s));
+    b->tiles_T = T; b->tiles_nt = (int32_t)nt; b->tiles_lmax = lmax; b->tiles_shared = b->shared_keys;
+    return EPI_OK;
+  };
+  if (use_hint && hinted && b->cols_owned && b->tiles_T == T && b->tiles_lmax == lmax && b->tiles_shared == b->shared_keys) {
+    // the batch owns its columns and the table of the last build was made for this tile size and these shared keys: it is
+    // still there (tiles, d_slot_tile); misc[0] gets the count the pass had left, which the caller compares as always
+    hipLaunchKernelGGL(k_misc_reset, dim3(1), dim3(64), 0, s, d_misc, b->tiles_nt_dev.as<uint32_t>());   // (one launch instead of three copies)
+    EPI_HIP(hipGetLastError());
+    *hinted = true;
+    *ntiles_out = b->tiles_nt;
+    return EPI_OK;
+  }
   if (use_hint && hinted && slot >= 0 && b->tile_hint_lmax[slot] == lmax) {
     // The tile count and the per-block offsets are functions of the batch's rows and T alone: with those of an earlier
     // call the table is allocated up front and filled by ONE pass that verifies them block by block; the caller
@@ -284,10 +309,12 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
                        b->d_slot_tile.as<int32_t>(), d_misc, (int64_t)nt);
     prof_end("tile_index", s);
     EPI_HIP(hipGetLastError());
+    EPI_TRY(remember_table(nt));
     *hinted = true;
     *ntiles_out = (int32_t)nt;
     return EPI_OK;
   }
+  b->tiles_T = 0;
   EPI_TRY(b->scan_tmp.ensure((size_t)nb * 4));
   uint32_t *bsum = b->scan_tmp.as<uint32_t>();
   hipLaunchKernelGGL((k_tile_pass<false>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
@@ -313,6 +340,7 @@ int build_tiles(epi_batch *b, hipStream_t s, int32_t T, RowStats *h, int32_t *nt
   hipLaunchKernelGGL((k_tile_pass<true>), dim3((unsigned)nb), dim3(TB_THREADS), 0, s, b->start, b->rname, b->n, lmax, sh, bsum,
                      b->tiles.as<Tile>(), b->d_shared_keys.as<int64_t>(), nshared, b->d_slot_tile.as<int32_t>(), d_misc, (int64_t)nt);
   EPI_HIP(hipGetLastError());
+  EPI_TRY(remember_table(nt));
   *ntiles_out = (int32_t)nt;
   return EPI_OK;
 }

@@ -180,7 +180,8 @@ def test_batch_changed_under_a_remembered_tile_count(ea):
     xm = torch.zeros((nb + 15) // 16 * 16, dtype=torch.uint8, device="cuda:0")
     xm[:nb] = torch.from_numpy(t["xm"]).cuda()
     bam = ea.ProcessedBam.from_device(xm, nb, torch.from_numpy(t["off"]).cuda(), torch.from_numpy(t["rname"]).cuda(),
-                                      torch.from_numpy(t["strand"]).cuda(), torch.from_numpy(t["start"]).cuda())
+                                      torch.from_numpy(t["strand"]).cuda(), torch.from_numpy(t["start"]).cuda(),
+                                      realign=False)         # strictly zero-copy: the engine reads the caller's columns every time
     try:
         for _ in range(2):                                   # the second call runs on the remembered count
             H.assert_reports_equal(dict(ea.rcpp_cx_report(bam, None, "Z")),
