@@ -110,7 +110,13 @@ struct RowStats {          // filled by k_row_stats
   int32_t bad_strand;      // !=0: strand not in {1,2}
   int32_t bad_len;         // !=0: off not non-decreasing
   int32_t deep;            // !=0: some position may be covered by more than 255 rows (row x + 255 starts inside row x)
+  // rows by the number of position-aligned 16-byte chunks a row can span, (len + 30) / 16: bin k counts the rows with at most
+  // kLenBins[k] chunks that did not fit bin k - 1 (the last bin: everything longer).  The tile kernels pick their lane shape
+  // from this, not from the longest row (one 1 kb template among 100 000 PE150 ones must not widen the shape for all).
+  uint32_t len_hist[14];
 };
+constexpr int kLenBinCount = 14;
+constexpr int kLenBins[kLenBinCount] = {12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 0x7FFFFFFF};
 }  // namespace epi
 
 struct epi_shard_plan;      // comm.hip: shared tile keys of a (batch, tile grid, communicator) triple
@@ -136,7 +142,7 @@ struct epi_batch {
   epi::DevBuf stats;        // RowStats of the batch (k_row_stats, queued once at creation)
   bool stats_queued = false, stats_host = false;
   hipEvent_t stats_done = nullptr;          // recorded behind k_row_stats on the stream it was queued on
-  epi::RowStats h_stats = {0, 0, 0, 0};   // host copy, fetched by the first report call (which raises the errors)
+  epi::RowStats h_stats = {};   // host copy, fetched by the first report call (which raises the errors)
   epi::DevBuf scan_tmp;
   epi::DevBuf tiles, tile_nrow, tile_base, tile_out;
   epi::DevBuf pool_key, pool_a, pool_b, pool_c, pool_d, pool_e, pool_f;

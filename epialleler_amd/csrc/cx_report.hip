@@ -230,9 +230,12 @@ __device__ __forceinline__ void cx2_mask_upto(int hi /* 1..16 */, uint32_t (&m)[
   m[0] = (uint32_t)a; m[1] = (uint32_t)(a >> 32); m[2] = (uint32_t)b; m[3] = (uint32_t)(b >> 32);
 }
 
-template <int T, int G, int NU, int NP, bool FUSED, class LT, class F>
+// MODE (fused only): 0 = the whole row is this one visit; a row of more chunks than the lane shape holds is worked on in
+// slices, twice: 1 = add the slice's class totals to `carry` (nothing else), then -- the decision made by the caller --
+// 2 = the calls of the slice with g.ps given.
+template <int T, int G, int NU, int NP, bool FUSED, int MODE = 0, class LT, class F>
 __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t cs, int32_t cz, int sub, int rcur,
-                                          const LT &L, F fetch_next) {
+                                          const LT &L, F fetch_next, uint32_t *carry = nullptr) {
   constexpr int C = LT::W / CX_CH, Q = LT::Q;                       // chunks / u64 cells per strand of the window (= the tile unless the workgroup walks)
   const int32_t cb = cs + sub;                                      // this lane's chunks: cb + u*G
   const int32_t tl = cz - cb;                                       // chunk u is part of the visit iff u*G <= tl
@@ -344,13 +347,22 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
         }
       }
     };
-    if (__builtin_expect(__ballot((fl & 0xAAAAAAAAu) != 0u) == 0ull, 1)) count(std::false_type{});
-    else count(std::true_type{});
-    const uint32_t s01 = cx2_group_sum<G>(cls[0] | (cls[1] << 16)), s23 = cx2_group_sum<G>(cls[2] | (cls[3] << 16));
-    const uint32_t n_all = s01 & 0xFFFFu, n_m = s01 >> 16;
-    g.ps = a.thr_tab ? cx2_threshold_tab(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr, a.thr_tab)
-                     : cx2_threshold(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr);
-    if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;   // by the tile the row starts in
+    if constexpr (MODE != 2) {
+      if (__builtin_expect(__ballot((fl & 0xAAAAAAAAu) != 0u) == 0ull, 1)) count(std::false_type{});
+      else count(std::true_type{});
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) carry[k] += cls[k];
+      return;
+    }
+    if constexpr (MODE == 0) {
+      const uint32_t s01 = cx2_group_sum<G>(cls[0] | (cls[1] << 16)), s23 = cx2_group_sum<G>(cls[2] | (cls[3] << 16));
+      const uint32_t n_all = s01 & 0xFFFFu, n_m = s01 >> 16;
+      g.ps = a.thr_tab ? cx2_threshold_tab(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr, a.thr_tab)
+                       : cx2_threshold(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr);
+      if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;   // by the tile the row starts in
+    }
     // calls: n = in-context bytes, M = methylated ones of a passing read (a failed read is lower-cased, :118)
     const uint32_t pm = g.ps ? 0x01010101u : 0u;
 #pragma unroll
@@ -483,7 +495,9 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
     RowVals nv;
     bool fetched = false;
     auto fetch_next = [&]() { if (!fetched) { nv = cx_load_row(a.c, tb, r); fetched = true; } };
-    if (v.ok && v.len > 0) {
+    // (a candidate row -- start within the longest row's reach in front of the tile -- that ends in front of the tile has
+    //  nothing for it; its pass flag is the business of the tile it starts in)
+    if (v.ok && v.len > 0 && (int32_t)((uint32_t)v.st - (uint32_t)td.pos0) + v.len > 0) {
       Cx2Row g;
       g.rel = (int32_t)((uint32_t)v.st - (uint32_t)td.pos0);
       g.len = v.len;
@@ -495,13 +509,30 @@ __device__ __forceinline__ void cx2_rows(const Cx2Args &a, const Tile &td, int r
       g.sidx = v.sd - 1;
       g.ps = v.ps;
       if constexpr (FUSED) {
-        cx2_visit<T, G, NU, NP, true>(a, g, g.c0, g.clast, sub, rcur, L, fetch_next);     // the host made sure the row fits
+        if (__builtin_expect(__ballot(g.clast - g.c0 >= G * NU) == 0ull, 1)) {
+          cx2_visit<T, G, NU, NP, true>(a, g, g.c0, g.clast, sub, rcur, L, fetch_next);   // every row of the step fits the lane shape
+        } else {
+          // A row of this step is longer than the shape holds (the host picks the shape for the bulk of the rows, pick_cx_shape):
+          // the whole step goes slice by slice, once for the class totals and -- every row decided -- once more for the calls.
+          uint32_t cls[4] = {0, 0, 0, 0};
+          for (int32_t cs = g.c0; __ballot(cs <= g.clast) != 0ull; cs += G * NU)
+            cx2_visit<T, G, NU, NP, true, 1>(a, g, cs, g.clast, sub, rcur, L, fetch_next, cls);
+          const uint32_t s01 = cx2_group_sum<G>(cls[0] | (cls[1] << 16)), s23 = cx2_group_sum<G>(cls[2] | (cls[3] << 16));
+          const uint32_t n_all = s01 & 0xFFFFu, n_m = s01 >> 16;
+          g.ps = a.thr_tab ? cx2_threshold_tab(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr, a.thr_tab)
+                           : cx2_threshold(n_m, n_all - n_m, s23 & 0xFFFFu, s23 >> 16, a.thr);
+          if (a.pass_out && sub == 0 && (uint32_t)g.rel < (uint32_t)T) a.pass_out[rcur] = g.ps;
+          // (calls only exist inside the tile: slices in front of it or behind it are not loaded again)
+          const int32_t ca = g.c0 > 0 ? g.c0 : 0, cz = g.clast < C - 1 ? g.clast : C - 1;
+          for (int32_t cs = ca; __ballot(cs <= cz) != 0ull; cs += G * NU)
+            cx2_visit<T, G, NU, NP, true, 2>(a, g, cs, cz, sub, rcur, L, fetch_next);
+        }
       } else {
         const int32_t ca = g.c0 > 0 ? g.c0 : 0, cz = g.clast < C - 1 ? g.clast : C - 1;   // the slice inside the tile
-        if constexpr (C + 1 <= 64 * NU) {                   // (the host picked G so that a slice is one visit: pick_cx_shape)
+        if (__builtin_expect(__ballot(cz - ca >= G * NU) == 0ull, 1)) {
           cx2_visit<T, G, NU, NP, false>(a, g, ca, cz, sub, rcur, L, fetch_next);
-        } else {
-          for (int32_t cs = ca; cs <= cz; cs += G * NU) cx2_visit<T, G, NU, NP, false>(a, g, cs, cz, sub, rcur, L, fetch_next);
+        } else {                                            // longer than the lane shape holds: several visits
+          for (int32_t cs = ca; __ballot(cs <= cz) != 0ull; cs += G * NU) cx2_visit<T, G, NU, NP, false>(a, g, cs, cz, sub, rcur, L, fetch_next);
         }
       }
       if (sub == 0) {                                                 // coverage: +1 on the row's positions inside the tile
@@ -1292,23 +1323,52 @@ static int cx_tile_for(int np) { return np <= 1 ? CX_T1 : CXP_T; }
 // The smallest G * NU that holds them wins: idle chunk slots cost the same VALU as used ones, and fewer lanes per row
 // are more rows per wavefront step (PE150: 20 chunks = 4 lanes x 5, against 8 x 3 = 24 slots).  Four to six chunks per
 // lane need ~80 VGPRs, which only the lean kernel's 256-thread workgroups have.  Returned as G * 8 + NU.
-static int pick_cx_shape(int32_t max_len, int T, bool fused, bool lean) {
-  const int64_t span = (fused ? (int64_t)max_len : (max_len < T ? max_len : T)) + (CX_CH - 1);
-  int chunks = (int)((span + CX_CH - 1) / CX_CH);
-  if (!fused && chunks > T / CX_CH) chunks = T / CX_CH;    // (a slice is clipped to the tile's position-aligned chunks: never more than T / 16)
+// Lane shape (G lanes per row, NU chunks per lane) of the single-context tile kernels, as G * 8 + NU: the one with the least
+// expected work per row over the batch's length histogram (RowStats::len_hist).  A row of g * nu chunks or fewer is one visit
+// and costs ~ g * nu chunk slots + its share of the step's set-up (~ 2 g); a longer row is worked on in slices -- with fused
+// thresholding twice, totals then calls -- and takes the 64 / g rows of its wavefront step along.  So the bulk of the rows
+// picks the shape and a tail of long templates pays for itself: one 1 kb template among 100 000 PE150 ones used to widen the
+// shape for all of them (config 2 with such a tail: 2.0 ms instead of 0.76, scratch/outlier_cost.py).
+static int pick_cx_shape(const RowStats &st, int T, bool fused, bool lean) {
 #ifdef EPI_CX_FORCE_SHAPE                                  // timing builds only: (G, NU) = (EPI_CX_FORCE_SHAPE / 8, % 8)
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
-  int best = 0, best_cap = 0;
+  const int max_chunks = (int)(((int64_t)st.max_len + 2 * (CX_CH - 1)) / CX_CH);
+  const int tile_chunks = T / CX_CH + 1;                   // (a slice of an un-thresholded report is clipped to the tile)
+  double total = 0;
+  for (int k = 0; k < kLenBinCount; k++) total += st.len_hist[k];
+  int best = 64 * 8 + 3;
+  double best_cost = -1;
   for (int g = (fused || lean) ? 4 : 8; g <= 64; g <<= 1)
     for (int nu = 3; nu <= (lean ? 6 : 3); nu++) {
       const int cap = g * nu;
-      if (cap < chunks) continue;
-      if (!best || cap < best_cap) { best = g * 8 + nu; best_cap = cap; }   // ties: the earlier (fewer lanes per row) wins
+      double extra = 0;
+      for (int k = 0; k < kLenBinCount; k++) {
+        if (!st.len_hist[k]) continue;
+        int ch = kLenBins[k] < max_chunks ? kLenBins[k] : max_chunks;
+        if (!fused && ch > tile_chunks) ch = tile_chunks;
+        const int slices = (ch + cap - 1) / cap;
+        if (slices > 1) extra += (total > 0 ? st.len_hist[k] / total : 1.0) * (fused ? 2 * slices - 1 : slices - 1);
+      }
+      if (total == 0) {                                    // (no histogram: by the longest row, as rounds 1-3 did)
+        int ch = max_chunks;
+        if (!fused && ch > tile_chunks) ch = tile_chunks;
+        if (cap < ch) continue;
+      }
+      const double cost = (cap + 2.0 * g) * (1.0 + (64 / g) * extra);
+      if (best_cost < 0 || cost < best_cost) { best = g * 8 + nu; best_cost = cost; }   // ties: the earlier (fewer lanes per row) wins
     }
-  return best ? best : 64 * 8 + 3;
+  return best;
 }
-static bool cx_fused_fits(int32_t max_len) { return ((int64_t)max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3; }
+// Fused thresholding decides a row from its whole length on every visit: for batches whose rows are (nearly all) short.  A
+// tail of long rows goes slice by slice (cx2_rows); a long-read batch takes the per-read kernel + the un-thresholded report.
+static bool cx_fused_fits(const RowStats &st) {
+  if (st.max_len >= 65000) return false;                   // (class totals of a row travel as 16-bit halves)
+  double total = 0, longer = 0;
+  for (int k = 0; k < kLenBinCount; k++) { total += st.len_hist[k]; if (kLenBins[k] > 64 * 3) longer += st.len_hist[k]; }
+  if (total == 0) return ((int64_t)st.max_len + 2 * (CX_CH - 1)) / CX_CH <= 64 * 3;
+  return longer <= 0.01 * total;
+}
 
 constexpr unsigned CX_HEAVY_CAP = 8, CX_HEAVY_GRID = 128;   // ultra-deep tiles finished without a host round trip, work items each
 constexpr unsigned CX_LIST_GRID = 512;        // workgroups of the general kernel behind a lean launch (they loop over the list)
@@ -1505,7 +1565,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   bool fused = false;
   if (thr) {
     uint32_t fill4 = 0;
-    if (nt > 0 && np > 0 && cx_fused_fits(st.max_len) && make_fused_lut(*thr, a.ctx_of_plane, np, &a.lut_s, &fill4)) {
+    if (nt > 0 && np > 0 && cx_fused_fits(st) && make_fused_lut(*thr, a.ctx_of_plane, np, &a.lut_s, &fill4)) {
       fused = true;
       a.lut_sx = lut16_xor_form(a.lut_s);
       a.thr = thr->prm;
@@ -1576,8 +1636,8 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   if (!options().cx_lean) lean = false;                    // test hook (EPIHIP_CX_LEAN=0): the general kernel for every tile
   const bool per_tile = lean && st.deep != 0;
   // lanes per row * 8 + chunks per lane; the heavy-tile kernel is the general one (three chunks per lane)
-  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st.max_len, T, fused, lean);
-  const int grp_heavy = np > 1 ? grp : pick_cx_shape(st.max_len, T, fused, false);
+  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st, T, fused, lean);
+  const int grp_heavy = np > 1 ? grp : pick_cx_shape(st, T, fused, false);
 
   // Walking workgroups (timing builds, EPI_CX_WALK_BUILD + EPIHIP_CX_WALK=K; lean kernel, rows of up to CX_PAD - 15 bytes = the
   // four-lane shapes): every row analysed once, by the tile it starts in.  Bit-exact, but slower than one tile per

@@ -22,6 +22,9 @@ __device__ __forceinline__ int64_t tile_of(int64_t pos, int32_t sh) { return (po
 __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ start, const int32_t *__restrict__ rname,
                                                     const int32_t *__restrict__ strand, const int64_t *__restrict__ off,
                                                     int64_t n, RowStats *__restrict__ st, int32_t *__restrict__ len_out) {
+  __shared__ uint32_t s_hist[kLenBinCount];
+  if (threadIdx.x < kLenBinCount) s_hist[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int len = 0, unsorted = 0, bad_strand = 0, bad_len = 0, deep = 0;
   if (x < n) {
@@ -41,7 +44,15 @@ __global__ __launch_bounds__(256) void k_row_stats(const int32_t *__restrict__ s
     // before start[x] + len[x].  So when row x + 255 starts at or behind the end of row x (for every x), no position is
     // covered by more than 255 rows, and u8 counters per position cannot overflow (cx_report.hip, LEAN).
     if (len > 0 && x + 255 < n && rname[x + 255] == rname[x] && (int64_t)start[x + 255] < (int64_t)s0 + len) deep = 1;
+    if (len > 0) {
+      const int ch = (len + 30) >> 4;
+      int k = 0;
+      while (k < kLenBinCount - 1 && ch > kLenBins[k]) k++;
+      atomicAdd(&s_hist[k], 1u);
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < kLenBinCount && s_hist[threadIdx.x]) atomicAdd(&st->len_hist[threadIdx.x], s_hist[threadIdx.x]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     len = max(len, __shfl_xor(len, d, 64));

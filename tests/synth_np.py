@@ -122,3 +122,18 @@ def generate_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_firs
         xs = np.arange(row_first, row_first + n, dtype=np.int64).astype(U64)
         strand = (1 + (hash3(seed, 2, xs) & U64(1)).astype(np.int64)).astype(np.int32)
     return {"xm": byte, "off": off, "rname": rname.astype(np.int32), "strand": strand, "start": start.astype(np.int32)}
+
+
+def with_long_tail(t, every, long_len, first=0):
+    """Every `every`-th row (from `first`) stretched to `long_len` bytes by repeating its own bytes: the bulk of the rows keeps its
+    length, the batch's longest row becomes long_len -- the shape of a paired-end library's insert-size tail."""
+    n = len(t["start"])
+    lens = np.diff(t["off"]).astype(np.int64)
+    rows = [t["xm"][t["off"][x]:t["off"][x + 1]] for x in range(n)]
+    for x in range(first, n, every):
+        if lens[x] > 0:
+            rows[x] = np.tile(rows[x], long_len // int(lens[x]) + 1)[:long_len]
+    out = dict(t)
+    out["off"] = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int64)
+    out["xm"] = np.concatenate(rows).astype(np.uint8) if n else t["xm"]
+    return out

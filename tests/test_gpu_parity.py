@@ -198,6 +198,18 @@ def test_batch_changed_under_a_remembered_tile_count(ea):
         bam.close()
 
 
+@pytest.mark.parametrize("every,long_len", [(97, 1000), (500, 2500), (13, 400), (301, 7000)])
+def test_tail_of_long_templates(ea, every, long_len):
+    # The lane shape of the tile kernels follows the bulk of the rows (length histogram), not the longest one: rows longer than
+    # the shape holds go slice by slice -- with fused thresholding twice (class totals, then calls) -- and take their wavefront
+    # step along; candidate rows that end in front of a tile are skipped.  Short rows + a tail, every function, every route.
+    rng = np.random.default_rng(every * 7 + long_len)
+    t = synth_np.with_long_tail(synth_np.random_templates(rng, 6000, 100, 310, 2, 60000), every, long_len, first=int(rng.integers(0, every)))
+    check_all(ea, t, contexts=("CG", "CHH"))
+    t = synth_np.with_long_tail(synth_np.generate_uniform(n_total=9000, mean_len=300, n_chr=2, ragged=False, gap_every=0), every, long_len)
+    check_all(ea, t, contexts=("CG",))
+
+
 def test_ragged_random(ea):
     rng = np.random.default_rng(11)
     for n, mx, span in ((1, 50, 100), (7, 40, 60), (300, 400, 3000), (2000, 700, 20000), (500, 33, 400)):
