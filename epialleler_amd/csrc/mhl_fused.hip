@@ -675,7 +675,15 @@ __global__ __launch_bounds__(WG, (mhlf_wps<WIDE, WG, FOLD>())) void k_mhl_fused(
       if (rr < bhi) { n_rs = a.off[rr]; n_re = n_rs + a.len[rr]; n_st = a.start[rr]; n_sd = a.strand[rr]; }
     };
     struct Geo { int32_t rel, len, sd; bool valid; };
-    auto geo_of = [&](int rr) { Geo g; g.rel = (int32_t)((uint32_t)n_st - (uint32_t)td.pos0); g.len = (int32_t)(n_re - n_rs); g.sd = n_sd; g.valid = rr < bhi; return g; };
+    // (a candidate row -- start within the longest row's reach in front of the tile -- that ends in front of the tile has nothing
+    //  for it.  Fast variant: the lane shape is picked for the bulk of the rows, pick_mhlf_shape_hist; a row it cannot hold sends
+    //  the tile to the WIDE variant, whose shape holds the batch's longest row.)
+    auto geo_of = [&](int rr) {
+      Geo g; g.rel = (int32_t)((uint32_t)n_st - (uint32_t)td.pos0); g.len = (int32_t)(n_re - n_rs); g.sd = n_sd;
+      g.valid = rr < bhi && g.rel + g.len > 0;
+      if constexpr (!WIDE) { if (g.valid && g.len + 15 > G * W) { g.valid = false; hmax = 0xFFFFFFFFu; } }
+      return g;
+    };
     auto load_bytes = [&](const Geo &g) {                   // (uses n_rs: call before the columns move on)
       const int32_t lo0 = (g.rel & 15) - sub * W;
       const int32_t g32 = (int32_t)((uint32_t)n_rs - (uint32_t)buf_base) - lo0;     // the lane's byte 0 in the descriptor
@@ -888,6 +896,35 @@ static int pick_mhlf_shape(int32_t max_len) {
   return best;
 }
 
+// The fast variant's lane shape from the batch's length histogram: a shape that holds rows of up to `cap` bytes costs ~ cap per
+// row (+ its share of the step); the tiles that see a longer row are done again by the WIDE variant with the shape for the
+// longest row.  One 1 kb template among 100 000 PE150 ones used to make every row pay for 1 kb (scratch/outlier_cost.py).
+static int pick_mhlf_shape_hist(const RowStats &st, int64_t n, int32_t nt, int T) {
+  const int wide = pick_mhlf_shape(st.max_len);
+  if (options().mhlf_shape) return wide;
+  double total = 0;
+  for (int k = 0; k < kLenBinCount; k++) total += st.len_hist[k];
+  if (total == 0 || nt <= 0 || !wide) return wide;
+  auto cost_of = [](int shape) { const int g = shape / 100, w = 16 * (shape / 10 % 10 + shape % 10); return (double)g * w + 8.0 * g; };
+  const double rows_per_tile = (double)n / nt, tiles_per_long = 1.0 + (double)st.max_len / T;
+  int best = wide;
+  double best_cost = cost_of(wide);
+  for (int k = 0; k < kLenBinCount - 1; k++) {
+    const int32_t len_k = kLenBins[k] * 16 - 15;             // the longest row of bin k: (len + 30) / 16 <= bound
+    if (len_k >= st.max_len) break;
+    const int shape = pick_mhlf_shape(len_k);
+    if (!shape) continue;
+    const int64_t cap = (int64_t)(shape / 100) * 16 * (shape / 10 % 10 + shape % 10);
+    double longer = 0;                                       // rows this shape cannot hold: len + 15 > cap
+    for (int j = 0; j < kLenBinCount; j++) if ((int64_t)kLenBins[j] * 16 > cap) longer += st.len_hist[j];
+    double aside = longer / total * rows_per_tile * tiles_per_long;
+    if (aside > 1.0) aside = 1.0;
+    const double c = cost_of(shape) + aside * 1.5 * cost_of(wide);
+    if (c < best_cost) { best = shape; best_cost = c; }
+  }
+  return best;
+}
+
 template <bool WIDE>
 static void launch_mhl_fused(int shape, unsigned grid, int nt, hipStream_t s, const MhlFArgs &a, bool fold = true) {
   const int g0 = shape / 100, ca = shape / 10 % 10, cb = shape % 10;
@@ -964,7 +1001,8 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     if (nshared > 0) return fail(EPI_ERR_STATE, "shared tiles were attached for the one-pass lMHL kernel, but this batch needs the two-kernel path");
     return EPI_OK;
   }
-  const int gc = pick_mhlf_shape(st.max_len);
+  const int gc_wide = pick_mhlf_shape(st.max_len);         // holds every row
+  const int gc = pick_mhlf_shape_hist(st, b->n, nt, T);    // the fast variant's: for the bulk of the rows
   uint32_t k = 0;
   for (uint32_t c : {2u, 6u, 7u}) if (ctx_mask == ((1u << c) | (1u << (c + 8)))) k = c;
   b->last_ntiles = nt;
@@ -1053,7 +1091,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
     // (the preference was learned for one H: S(min(h, H)) shrinks with H, so a report with a smaller H starts on the fast
     //  variant again, which lists the tiles that still need the wide sums)
     const bool wide_first = b->mhlf_prefer_wide && H >= b->mhlf_prefer_wide_H;
-    if (wide_first) launch_mhl_fused<true>(gc, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a, fold);
+    if (wide_first) launch_mhl_fused<true>(gc_wide, grid, nt, s, a); else launch_mhl_fused<false>(gc, grid, nt, s, a, fold);
     prof_end("mhl_tiles", s);
     EPI_HIP(hipGetLastError());
     EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
@@ -1067,7 +1105,7 @@ int mhl_fused_report(epi_batch *b, uint32_t ctx_mask, uint32_t H, int hmin, doub
       // tiles the fast variant set aside (too many rows, sums that could wrap u32): the WIDE variant redoes exactly those
       a.tile_list = a.deep_list;
       prof_begin("mhl_deep", s);
-      launch_mhl_fused<true>(gc, host4[3], (int)host4[3], s, a);
+      launch_mhl_fused<true>(gc_wide, host4[3], (int)host4[3], s, a);
       prof_end("mhl_deep", s);
       EPI_HIP(hipGetLastError());
       EPI_TRY(scan_exclusive_u32(a.tile_nrow, b->tile_out.as<uint32_t>(), nt, cursor + 1, b->scan_tmp, s));
