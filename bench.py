@@ -23,8 +23,9 @@ Besides the contract line's `value` (inputs resident in HBM) the N=1 line carrie
   n1_same_stream  the step at N=1 on the 3-chromosome stream the N>1 runs use (the base for a 1 -> N ratio)
   sharded_1rank  the same step through epi_batch_cytosine_report_sharded (RCCL inside the library) on one rank: 14 forced shared
              tiles + a real ncclAllReduce
-  cfg2g / cfg2u / cfg2p   the stream's effects apart: round 1/2's jittered-grid starts / ragged lengths and gapped
-             mates / one 20 000-row pile-up in the stream
+  cfg2g / cfg2u / cfg2p / cfg2t   the stream's effects apart: round 1/2's jittered-grid starts / ragged lengths and gapped
+             mates / one 20 000-row pile-up in the stream / one template in 1000 stretched to 1 kb (the lane shapes follow the
+             bulk of the rows, not the longest one)
   strong_cfg3  BASELINE config 3 (100 M templates in total, split over the N GPUs)
 and every N>1 run first checks, on a reduced-size stream whose cuts lie inside chromosomes, that the sharded tables equal
 the single-GPU tables and that the shared-tile exchange really carried bytes.
@@ -55,6 +56,8 @@ WORKLOADS = {
                   desc="as cfg2 with template lengths 240-360 and a 50-byte 0xFB gap in every fourth template"),
     "cfg2p": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="uniform", pileup=20_000,
                   desc="as cfg2 with one 20 000-row pile-up (all rows starting at one position) in the middle of the stream"),
+    "cfg2t": dict(rows=10_000_000, read_len=300, kind="cx", threshold=True, report_context="CG", stream="uniform", tail=(1000, 1000),
+                  desc="as cfg2 with one template in 1000 stretched to 1000 bytes (an insert-size tail: the batch's longest row is 1 kb)"),
     "cfg2n": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CG", stream="uniform",
                   desc="10M PE150 templates, generateCytosineReport(threshold.reads=FALSE): SURVEY 8d's un-thresholded config 2"),
     "cfg2cx": dict(rows=10_000_000, read_len=300, kind="cx", threshold=False, report_context="CX", stream="uniform",
@@ -200,6 +203,8 @@ def make_batch(cx, wl, rows, L, n_total, seed=42, n_chr=None):
         return cx.synth.generate_device(read_len=L, **kw)
     if wl.get("pileup"):
         kw["pileup"] = (n_total // 2 + 1234, int(wl["pileup"]))
+    if wl.get("tail"):
+        kw["tail"] = wl["tail"]
     if stream == "ragged":
         return cx.synth.generate_device_uniform(mean_len=L, **kw)
     return cx.synth.generate_device_uniform(mean_len=L, ragged=False, gap_every=0, **kw)
@@ -322,6 +327,8 @@ def n1_selfcheck(cx, wl, res, L):
     rows = res["rows"]
     if wl.get("stream") == "ragged":
         L = L * 6 // 5                                     # template lengths 0.8-1.2 L: the trimmed margin is the LONGEST read
+    if wl.get("tail"):
+        L = max(L, int(wl["tail"][1]))
     wrows = 20000 if L <= 1000 else max(300, 20000 * 300 // L)
     letters = {"CG": "Z", "CHG": "X", "CHH": "H", "CxG": "ZX", "CX": "ZXH"}[wl.get("report_context", "CG")]
     fn = W.oracle_for(wl["kind"], wl.get("threshold", False), letters)
@@ -718,7 +725,7 @@ def main():
     if extras and args.workload == "cfg2":
         if world == 1:
             k2 = max(3, args.steps // 2)
-            for name in ("cfg2g", "cfg2u", "cfg2p"):     # the three effects apart: start distribution / ragged + gaps / a pile-up
+            for name in ("cfg2g", "cfg2u", "cfg2p", "cfg2t"):     # the effects apart: start distribution / ragged + gaps / a pile-up / a tail of long templates
                 u = timed_run(cx, WORKLOADS[name], rows, L, k2, 1)
                 if out is not None:
                     out[name] = {"value": round(u["n_total"] * k2 / u["dt"] / 1e6, 3), "unit": "Mreads/s",

@@ -103,7 +103,7 @@ def uniform_layout(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=
 
 
 def generate_device_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, row_first=0, n=None,
-                            gap_every=4, gap_len=50, device=None, ragged=True, pileup=None):
+                            gap_every=4, gap_len=50, device=None, ragged=True, pileup=None, tail=None):
     """Rows [row_first, row_first+n) of the uniform-start stream, resident on `device`.  bench: cfg2 / cfg3 / cfg4 / cfg5
     with ragged=False, gap_every=0 (uniform-random starts then sort, fixed L); cfg2u with the defaults
     (ragged lengths, a 0xFB gap between the mates of every fourth template)."""
@@ -114,6 +114,10 @@ def generate_device_uniform(n_total, mean_len=300, n_chr=4, depth=30, seed=42, r
     n = n_total - row_first if n is None else n
     dev = "cuda:%d" % device
     rname, start, lens = uniform_layout(n_total, mean_len, n_chr, depth, seed, row_first, n, dev, ragged, pileup)
+    if tail is not None and n:                               # (every, bytes): a paired-end library's insert-size tail -- one template
+        every, long_len = int(tail[0]), int(tail[1])         # in `every` (by global row id) is `bytes` long
+        first = (-row_first) % every
+        lens[torch.arange(first, n, every, device=dev)] = long_len
     off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=off[1:])
     nbytes = int(off[-1].item()) if n else 0
