@@ -54,6 +54,9 @@ while time.time() < t_end:
         t = synth_np.generate_uniform(seed=seed, n_total=int(rng.integers(1000, 30000)))
     else:              # the bench generator's model, small
         t = synth_np.generate(seed=seed, n_total=int(rng.integers(1000, 30000)), read_len=int(rng.choice([100, 300, 301, 2000])))
+    if kind in (0, 1, 3, 5) and rng.random() < 0.4 and t["off"].size > 2:      # a tail of long templates (lane shapes follow the bulk of the rows)
+        every = int(rng.choice([3, 17, 97, 501, 4001]))
+        t = synth_np.with_long_tail(t, every, int(rng.choice([330, 400, 650, 1000, 1100, 2500, 4000, 9000])), first=int(rng.integers(0, every)))
     n = t["off"].size - 1
     bam = ea.ProcessedBam.from_arrays(t["xm"], t["off"], t["rname"], t["strand"], t["start"])
     try:
