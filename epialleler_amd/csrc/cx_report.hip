@@ -1423,6 +1423,24 @@ static int pick_cxp_group(int32_t max_len) {
   while (g < 64 && g * CX_NU < nd) g <<= 1;
   return g;
 }
+// ... for the bulk of the rows (cxp_accumulate walks the rest of a longer slice dword by dword): the smallest group that
+// holds all but 0.5 % of the rows in one pass, never wider than the longest row needs
+static int pick_cxp_group(const RowStats &st) {
+  const int by_max = pick_cxp_group(st.max_len);
+  double total = 0;
+  for (int k = 0; k < kLenBinCount; k++) total += st.len_hist[k];
+  if (total == 0) return by_max;
+  for (int g = 8; g < by_max; g <<= 1) {
+    double longer = 0;
+    for (int k = 0; k < kLenBinCount; k++) {
+      const int64_t len_k = (int64_t)kLenBins[k] * 16 - 15;                 // the longest row of bin k
+      const int64_t slice = (len_k < CXP_T ? len_k : CXP_T) + 3;
+      if ((slice + 3) / 4 > (int64_t)g * CX_NU) longer += st.len_hist[k];
+    }
+    if (longer <= 0.005 * total) return g;
+  }
+  return by_max;
+}
 
 static void launch_cxp(bool heavy, int np, int g, int nt, dim3 grid, hipStream_t s, const Cx2Args &a) {
   if (!heavy) {
@@ -1636,7 +1654,7 @@ static int cx_report_impl(epi_batch *b, const int32_t *d_pass, const CxThreshold
   if (!options().cx_lean) lean = false;                    // test hook (EPIHIP_CX_LEAN=0): the general kernel for every tile
   const bool per_tile = lean && st.deep != 0;
   // lanes per row * 8 + chunks per lane; the heavy-tile kernel is the general one (three chunks per lane)
-  const int grp = np > 1 ? pick_cxp_group(st.max_len) * 8 : pick_cx_shape(st, T, fused, lean);
+  const int grp = np > 1 ? pick_cxp_group(st) * 8 : pick_cx_shape(st, T, fused, lean);
   const int grp_heavy = np > 1 ? grp : pick_cx_shape(st, T, fused, false);
 
   // Walking workgroups (timing builds, EPI_CX_WALK_BUILD + EPIHIP_CX_WALK=K; lean kernel, rows of up to CX_PAD - 15 bytes = the
