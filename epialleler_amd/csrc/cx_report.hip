@@ -1334,7 +1334,7 @@ static int pick_cx_shape(const RowStats &st, int T, bool fused, bool lean) {
   if (fused) return EPI_CX_FORCE_SHAPE;
 #endif
   const int max_chunks = (int)(((int64_t)st.max_len + 2 * (CX_CH - 1)) / CX_CH);
-  const int tile_chunks = T / CX_CH + 1;                   // (a slice of an un-thresholded report is clipped to the tile)
+  const int tile_chunks = T / CX_CH;                       // (a slice of an un-thresholded report is clipped to the tile's position-aligned chunks)
   double total = 0;
   for (int k = 0; k < kLenBinCount; k++) total += st.len_hist[k];
   int best = 64 * 8 + 3;
