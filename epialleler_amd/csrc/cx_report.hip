@@ -262,9 +262,10 @@ __device__ __forceinline__ void cx2_visit(const Cx2Args &a, Cx2Row &g, int32_t c
   } else {
     const uint8_t *p = g.base + CX_CH * (int64_t)cb;
     {                                                     // (check build) every chunk this lane loads lies inside the buffer
-      const int64_t a_lo = p - a.c.xm, a_hi = a_lo + (tl >= 0 ? CX_CH * (int64_t)((tl / G) * G) + CX_CH : 0);
+      const int32_t uq = tl / G < NU - 1 ? tl / G : NU - 1;   // the lane's last chunk of THIS visit (a longer row goes on in the next slice)
+      const int64_t a_lo = p - a.c.xm, a_hi = a_lo + (tl >= 0 ? CX_CH * (int64_t)(uq * G) + CX_CH : 0);
       (void)a_lo; (void)a_hi;
-      if (!EPI_DEV_CHECK(a.dbg, tl < 0 || (a_lo >= 0 && a_hi <= a.xm_cap && (tl / G) < NU), 21, a_lo, a_hi)) return;
+      if (!EPI_DEV_CHECK(a.dbg, tl < 0 || (a_lo >= 0 && a_hi <= a.xm_cap), 21, a_lo, a_hi)) return;
     }
     if (EPI_CX_ABLATE & 1) p = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
 #pragma unroll
