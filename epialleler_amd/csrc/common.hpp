@@ -260,7 +260,7 @@ struct Options {
   int cx_walk = 0;           // EPIHIP_CX_WALK=K     timing builds with -DEPI_CX_WALK_BUILD only: K consecutive tiles per workgroup of the lean CX kernel
   int heavy_rows = 0;        // EPIHIP_HEAVY_ROWS    candidate rows above which a tile is split / set aside (0: default)
   int tile_hint = 1;         // EPIHIP_TILE_HINT=0   tile index counted and scanned by every call
-  int realign = 16;          // EPIHIP_REALIGN=0/4/16  epi_batch_upload / epi_batch_realign: keep the rows back to back / start them at
+  int realign = 16;          // EPIHIP_REALIGN=0/4/8/16 epi_batch_upload / epi_batch_realign: keep the rows back to back / start them at
                              //                      offsets congruent to their start position modulo 4 / 16 (layout.hip)
   int mhl_fused = 1;         // EPIHIP_MHL_FUSED=0   two-kernel lMHL path for every batch
   int mhl_slot = -1;         // EPIHIP_MHL_SLOT

@@ -40,7 +40,7 @@ static void read_options() {
   if (o.heavy_rows < 0) o.heavy_rows = 0;
   if (const char *e = getenv("EPIHIP_TILE_HINT")) o.tile_hint = atoi(e) != 0;
   geti("EPIHIP_REALIGN", &o.realign);
-  if (o.realign != 0 && o.realign != 4) o.realign = 16;
+  if (o.realign != 0 && o.realign != 4 && o.realign != 8) o.realign = 16;
   if (const char *e = getenv("EPIHIP_MHL_FUSED")) o.mhl_fused = atoi(e) != 0;
   geti("EPIHIP_MHL_SLOT", &o.mhl_slot);
   geti("EPIHIP_MHL_WG", &o.mhl_wg);

@@ -186,7 +186,7 @@ int layout_offsets(epi_batch *b, int modulus, hipStream_t s, DevBuf *new_off, un
 }
 
 int realign_batch(epi_batch *b, int modulus, hipStream_t s) {
-  if (modulus != 4 && modulus != 16) return fail(EPI_ERR_ARG, "realign: modulus must be 4 or 16");
+  if (modulus != 4 && modulus != 8 && modulus != 16) return fail(EPI_ERR_ARG, "realign: modulus must be 4, 8 or 16");
   if (b->congruent == modulus || b->n == 0) { b->congruent = modulus; return EPI_OK; }
   if (!b->stats_queued || !b->len) return fail(EPI_ERR_STATE, "realign: the batch has no row lengths yet");
   if (b->last_kind != 0) return fail(EPI_ERR_STATE, "epi_batch_realign: call it before the first report on the batch");

@@ -204,7 +204,7 @@ int epi_batch_adopt(epi_engine *e, const uint8_t *d_xm, int64_t xm_capacity, int
  * start is the engine's business.  epi_batch_upload does this itself; for an adopted batch it is the caller's call:
  * afterwards the batch no longer reads d_xm / d_off (the caller may free them), and holds B + <= 15 n bytes of its own.
  * Call it before the first report on the batch.  Results never depend on it.  EPIHIP_REALIGN=0 makes it a no-op
- * (A/B runs); 4 = congruent modulo 4 only.  epi_batch_layout: 0 = as given, 4 / 16 = congruent modulo that. */
+ * (A/B runs); 4 / 8 = congruent modulo 4 / 8 only.  epi_batch_layout: 0 = as given, 4 / 16 = congruent modulo that. */
 int epi_batch_realign(epi_batch *b, void *stream);
 int epi_batch_layout(const epi_batch *b);
 /* The rows as the kernels read them: row x owns d_xm[d_off[x] .. d_off[x] + d_len[x]) (d_off: n + 1 non-decreasing
