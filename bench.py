@@ -240,7 +240,17 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
     # setup, not steps: the first calls size the engine's row pool / record space for this workload and the caching
     # allocator's blocks for the two output tables that are alive at a time (rep = step() frees the previous one late)
     rep = step()
+    cx.torch.cuda.synchronize()
+    t0 = time.perf_counter()
     rep = step()
+    cx.torch.cuda.synchronize()
+    # ... and the GPU's clocks: a process that has queued a few milliseconds of work is timed 3-4 % slower than one that has been
+    # busy for a quarter of a second (profiles/r04_layout.txt, section 7), so the step runs untimed for ~0.3 s first -- the same
+    # count on every rank (the sharded step has collectives) -- whatever --warmup says
+    n_ramp = int(0.3 / max(cx.max_over_ranks(time.perf_counter() - t0), 1e-4))
+    n_ramp = max(5, min(n_ramp, 400))
+    for _ in range(n_ramp):
+        rep = step()
     for _ in range(warmup):
         rep = step()
     cx.barrier()
@@ -261,7 +271,7 @@ def timed_run(cx, wl, rows, L, steps, warmup, gather=False, keep=False, n_chr=No
             kernels[nm.decode()] = round(m2.value / c2.value, 4)
     nrow_local = rep.nrow if rep is not None else 0
     out = dict(dt=dt, ms_per_step=dt / steps * 1e3, n_total=n_total, rows=rows, L=L, kernels=kernels, native_comm=bool(native),
-               batch_ms=batch_ms, layout=int(cx.lib.epi_batch_layout(bam.batch())),
+               batch_ms=batch_ms, layout=int(cx.lib.epi_batch_layout(bam.batch())), ramp_steps=n_ramp,
                nrow_local=nrow_local, nbytes_local=bam.nbytes,
                exchange_bytes=getattr(eng, "last_exchange_bytes", 0) if eng is not None else 0)
     if keep:
@@ -684,7 +694,9 @@ def main():
                        "layout": ("rows at offsets congruent to their start position modulo %d in the engine's own copy of xm, made once per "
                                   "batch by epi_batch_realign (batch_ms below; layout_off: the step without it)" % res["layout"]) if res.get("layout")
                                  else "rows back to back as adopted",
-                       "batch_ms": round(res["batch_ms"], 3), "tile_index": ("the batch owns its columns (epi_batch_realign / epi_batch_upload): the tile table of the first report is kept, steps only reset its counters "
+                       "batch_ms": round(res["batch_ms"], 3),
+                       "setup": "%d untimed steps (~0.3 s) before the --warmup steps, so that the timed steps see sustained clocks" % res["ramp_steps"],
+                       "tile_index": ("the batch owns its columns (epi_batch_realign / epi_batch_upload): the tile table of the first report is kept, steps only reset its counters "
                                       "(tile_hint_off: EPIHIP_TILE_HINT=0, counted, scanned and filled by every step)" if res.get("layout") else
                                       "rebuilt by every step from all rows; block offsets remembered from the first call on the batch and verified block by block "
                                       "(EPIHIP_TILE_HINT=0: counted and scanned every step)"), "sharding": ("row ranges; shared tiles all-reduced (%s); output rows %s"
