@@ -310,9 +310,13 @@ def _exchange_ranges(engine, kind, group, ctx="Z"):
 
 
 def _gather_rows(tensors, group, world, rank, dev):
-    """Concatenates [k, n_r] tensors of all ranks on rank 0, in rank order (None elsewhere)."""
+    """Concatenates [k, n_r] tensors of all ranks on rank 0, in rank order (None elsewhere).  Point-to-point messages of
+    the gloo backend read and write the tensor's memory from the host, outside any stream: device tensors go through host
+    copies there (`.cpu()` waits for the kernels that fill them -- sending the device tensor raced with the table's gather
+    kernel); RCCL (backend nccl) sends from the device, in stream order."""
     import torch
     import torch.distributed as dist
+    host = dist.get_backend(group) != "nccl"
     cnt = torch.tensor([tensors[0].shape[1]], dtype=torch.int64, device=dev)
     cnts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
@@ -320,7 +324,7 @@ def _gather_rows(tensors, group, world, rank, dev):
     if rank != 0:
         if tensors[0].shape[1]:
             for t in tensors:
-                dist.send(t.contiguous(), dst=0, group=group)
+                dist.send(t.contiguous().cpu() if host else t.contiguous(), dst=0, group=group)
         return None
     outs = [torch.empty((t.shape[0], sum(cnts)), dtype=t.dtype, device=dev) for t in tensors]
     for o, t in zip(outs, tensors):
@@ -329,9 +333,9 @@ def _gather_rows(tensors, group, world, rank, dev):
     for r in range(1, world):
         if cnts[r]:
             for o in outs:
-                buf = torch.empty((o.shape[0], cnts[r]), dtype=o.dtype, device=dev)
+                buf = torch.empty((o.shape[0], cnts[r]), dtype=o.dtype, device="cpu" if host else dev)
                 dist.recv(buf, src=r, group=group)
-                o[:, pos:pos + cnts[r]] = buf
+                o[:, pos:pos + cnts[r]] = buf.to(dev) if host else buf
             pos += cnts[r]
     return outs
 
@@ -416,26 +420,10 @@ def sharded_cx_report(engine, pass_, ctx, group=None, gather=True, levels=None, 
     names = ("rname", "strand", "pos", "context", "meth", "unmeth")
     if not gather or world == 1:
         return Report({k: cols[i] for i, k in enumerate(names)}, levels)
-    # rows -> rank 0, concatenated in rank order
-    cnt = torch.tensor([cols.shape[1]], dtype=torch.int64, device=dev)
-    cnts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    cnts = [int(c.item()) for c in cnts]
-    if rank == 0:
-        total = sum(cnts)
-        out = torch.empty((6, total), dtype=torch.int32, device=dev)
-        out[:, :cnts[0]] = cols
-        o = cnts[0]
-        for r in range(1, world):
-            if cnts[r]:
-                buf = torch.empty((6, cnts[r]), dtype=torch.int32, device=dev)
-                dist.recv(buf, src=r, group=group)
-                out[:, o:o + cnts[r]] = buf
-                o += cnts[r]
-        return Report({k: out[i] for i, k in enumerate(names)}, levels)
-    if cols.shape[1]:
-        dist.send(cols.contiguous(), dst=0, group=group)
-    return None
+    got = _gather_rows([cols], group, world, rank, dev)               # rows -> rank 0, concatenated in rank order
+    if got is None:
+        return None
+    return Report({k: got[0][i] for i, k in enumerate(names)}, levels)
 
 
 def sharded_cytosine_report(engine, threshold_reads=True, threshold_context="CG", min_context_sites=2,

@@ -33,6 +33,8 @@ def _case(name):
         return synth_np.generate(n_total=9000, read_len=300, n_chr=3)
     if name == "amplicon":
         return synth_np.random_templates(rng, 4000, 100, 400, 1, 30)
+    if name == "wgs_tail":                                  # a tail of long templates: ranks may pick different lane shapes, shared tiles see sliced rows
+        return synth_np.with_long_tail(synth_np.generate(n_total=9000, read_len=300, n_chr=3), 61, 1100, first=7)
     return synth_np.random_templates(rng, 2500, 0, 3000, 3, 9000)       # long reads, 3 rnames
 
 
@@ -70,7 +72,7 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name", [(2, "wgs"), (3, "amplicon"), (2, "mixed"), (3, "wgs_empty"), (3, "amplicon_empty")])
+@pytest.mark.parametrize("world,name", [(2, "wgs"), (3, "amplicon"), (2, "mixed"), (3, "wgs_empty"), (3, "amplicon_empty"), (3, "wgs_tail")])
 def test_sharded_equals_oracle(tmp_path, world, name):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
